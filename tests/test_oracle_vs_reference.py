@@ -1,0 +1,109 @@
+"""The oracle (oracle/pt_oracle.cpp, my CPU restatement) against golden vectors produced by the
+UNMODIFIED reference (oracle/_ref, generator oracle/make_golden.py). CPU only.
+
+Bar: bit-exact for everything built from IEEE +,-,*,/,sqrt (geometry, KD build, traversal,
+hit attributes); <= 2 ulp where libm sin/cos/acos/pow are involved.
+"""
+import numpy as np
+import pytest
+
+from conftest import ulp_diff
+
+
+def test_loader_matches_reference_scene(cornell_arrays, gold_scene):
+    a, g = cornell_arrays, gold_scene
+    assert a.model_names == bytes(g["model_names"]).decode().split()
+    np.testing.assert_array_equal(a.model_xform, g["model_xform"])
+    np.testing.assert_array_equal(a.model_surf, g["model_surf"])
+    np.testing.assert_array_equal(a.surf_range, g["surf_range"][:, :4])
+    np.testing.assert_array_equal(a.vertices, g["vertices"])      # includes the Q1 tangent mis-stride
+    np.testing.assert_array_equal(a.triangles, g["triangles"])
+    np.testing.assert_array_equal(a.materials, g["materials"])
+    np.testing.assert_array_equal(a.material_tex, g["material_tex"])
+    np.testing.assert_array_equal(a.camera, g["camera"])
+    assert a.sun is None and g["sun"].size == 0
+
+
+def test_aabbs_match_reference(cornell_oracle, gold_scene):
+    mb, sb = cornell_oracle.boxes()
+    np.testing.assert_array_equal(mb, gold_scene["model_aabb"])
+    np.testing.assert_array_equal(sb, gold_scene["mesh_aabb"])   # includes the Q2 aabb::clear quirk (red wall max.x = 1e-4)
+    assert sb[3, 3] == np.float32(1e-4)
+
+
+def test_kd_trees_match_reference(cornell_oracle, gold_scene):
+    g = gold_scene
+    for s in range(cornell_oracle.n_surf):
+        k0, nk, r0, nr = g["surf_range"][s, 4:8]
+        kd = cornell_oracle.kd(s)
+        assert len(kd["type"]) == nk and len(kd["refs"]) == nr
+        sl = slice(k0, k0 + nk)
+        np.testing.assert_array_equal(kd["type"], g["kd_type"][sl])
+        br = kd["type"] == 0
+        np.testing.assert_array_equal(kd["axis"][br], g["kd_axis"][sl][br])
+        np.testing.assert_array_equal(kd["split"][br], g["kd_split"][sl][br])
+        gl, gr = g["kd_left"][sl], g["kd_right"][sl]
+        np.testing.assert_array_equal(kd["left"], np.where(gl < 0, -1, gl - k0))
+        np.testing.assert_array_equal(kd["right"], np.where(gr < 0, -1, gr - k0))
+        lf = ~br
+        np.testing.assert_array_equal(kd["first"][lf], g["kd_first"][sl][lf] - r0)
+        np.testing.assert_array_equal(kd["count"][lf], g["kd_count"][sl][lf])
+        np.testing.assert_array_equal(kd["refs"], g["kd_refs"][r0:r0 + nr])
+    assert g["kd_depth"].max() <= 26
+
+
+def test_triangle_intersect_bit_exact(ora, gold_vec):
+    out = ora.tri_intersect(gold_vec["tri_in"])
+    ref = gold_vec["tri_out"]
+    assert (ref[:, 0] >= 0).sum() > 200            # the fixture does exercise hits
+    np.testing.assert_array_equal(out.view(np.uint32), ref.view(np.uint32))
+
+
+def test_aabb_intersect_bit_exact(ora, gold_vec):
+    out = ora.aabb_intersect(gold_vec["aabb_in"])
+    ref = gold_vec["aabb_out"]
+    assert 100 < (ref[:, 0] > 0).sum() < len(ref)
+    np.testing.assert_array_equal(out.view(np.uint32), ref.view(np.uint32))
+
+
+def test_mesh_intersect_bit_exact(cornell_oracle, gold_vec):
+    rays, ref, idx = gold_vec["mesh_in"], gold_vec["mesh_out"], gold_vec["mesh_idx"]
+    for s in range(cornell_oracle.n_surf):
+        m = idx[:, 1] == s
+        out, oi = cornell_oracle.mesh_intersect(s, rays[m])
+        assert (idx[m, 0] >= 0).sum() > 50
+        np.testing.assert_array_equal(oi, idx[m, 0])
+        np.testing.assert_array_equal(out.view(np.uint32), ref[m].view(np.uint32))
+
+
+def test_model_intersect_bit_exact(cornell_oracle, gold_vec):
+    rays = gold_vec["world_rays"]
+    for mdl in range(cornell_oracle.n_models):
+        out, oi = cornell_oracle.model_intersect(mdl, rays)
+        np.testing.assert_array_equal(oi, gold_vec["model_idx"][:, mdl])
+        np.testing.assert_array_equal(out.view(np.uint32), gold_vec["model_out"][:, mdl].view(np.uint32))
+
+
+def test_scene_intersect_bit_exact(cornell_oracle, gold_vec):
+    out, oi = cornell_oracle.intersect(gold_vec["world_rays"])
+    assert (gold_vec["scene_idx"] >= 0).mean() > 0.5
+    np.testing.assert_array_equal(oi, gold_vec["scene_idx"])
+    np.testing.assert_array_equal(out.view(np.uint32), gold_vec["scene_out"].view(np.uint32))
+
+
+def test_pbr_functions(ora, gold_vec):
+    out = ora.pbr(gold_vec["pbr_in"])
+    ref = gold_vec["pbr_out"]
+    # columns: rand_cone_vec(3) importance_diffuse(3) importance_specular(3) pdf_d pdf_s fresnel reflect(3)
+    # The oracle calls the same libm (glibc) in the same order, so it is bit-exact here.
+    np.testing.assert_array_equal(out.view(np.uint32), ref.view(np.uint32))
+
+
+def test_camera_rays_bit_exact(cornell_oracle, gold_vec):
+    out = cornell_oracle.camera_rays(gold_vec["cam_in"])
+    np.testing.assert_array_equal(out.view(np.uint32), gold_vec["cam_out"].view(np.uint32))
+
+
+def test_tonemap_write_bytes_exact(ora, gold_vec):
+    out = ora.tonemap_write(gold_vec["tone_in"])
+    np.testing.assert_array_equal(out, gold_vec["tone_out"])
