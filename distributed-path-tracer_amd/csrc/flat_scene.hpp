@@ -1,0 +1,104 @@
+// Pointer-free scene layout shared by the host builder and the HIP kernels.
+//
+// The reference keeps the scene as a shared_ptr graph (entity -> model -> surfaces -> mesh ->
+// kd_tree_node, LIB/scene/entity.hpp, LIB/core/kd_tree.hpp:20-31). Here everything is a flat array:
+// fixed-size records for models / surfaces / materials (read with scalar loads: the loop index is
+// wave-uniform), 8-byte KD nodes, 4-byte leaf references and 48-byte triangle records (the three
+// arrays the kernels stage through LDS), and 32-byte vertex attribute records that stay in HBM/L2.
+#pragma once
+#include <cstdint>
+#include <vector>
+#include <string>
+
+namespace ptx {
+
+// ---- KD node: 2 dwords -------------------------------------------------------------------------
+// word1[1:0] = kind: 0,1,2 = branch on that axis, 3 = leaf
+// branch: word0 = split plane (float bits); word1 bit2 = has_left, bit3 = has_right,
+//         word1[31:4] = index of the first existing child; the right child sits at +has_left.
+//         (a missing child is the reference's nullptr child, mesh.cpp:227-241)
+// leaf:   word0 = index of the first leaf reference; word1[31:2] = reference count
+struct KdNode { uint32_t w0, w1; };
+constexpr uint32_t KD_LEAF = 3u;
+inline KdNode kd_make_branch(float split, uint32_t axis, bool has_l, bool has_r, uint32_t first_child) {
+	uint32_t bits;
+	__builtin_memcpy(&bits, &split, 4);
+	return {bits, axis | (has_l ? 4u : 0u) | (has_r ? 8u : 0u) | (first_child << 4)};
+}
+inline KdNode kd_make_leaf(uint32_t first_ref, uint32_t count) { return {first_ref, KD_LEAF | (count << 2)}; }
+
+// ---- triangle record: 3 x float4 (48 B, 16-B aligned so that each corner is one ds_read_b128) ----
+// xyz = corner position (mesh-local space), w = bit pattern of the GLOBAL vertex id of that corner
+struct TriRec { float ax, ay, az; uint32_t ia; float bx, by, bz; uint32_t ib; float cx, cy, cz; uint32_t ic; };
+
+// ---- vertex attributes: 2 x float4 (32 B) — normal.xyz, u | tangent.xyz, v ----
+struct VertAttr { float nx, ny, nz, u, tx, ty, tz, v; };
+
+// ---- per-model record (scene::model + its entity's global transform) ----
+struct ModelRec {
+	float inv_basis[9];   // columns x,y,z of inverse(basis)            — transform::inverse, transform.cpp:33-36
+	float inv_origin[3];  // inverse(basis) * -origin
+	float basis[9];       // columns of the global basis (local -> world; distance conversion model.cpp:62-63)
+	float origin[3];
+	float nmat[9];        // columns of transpose(inverse(basis))        — renderer.cpp:698
+	float bmin[3], bmax[3];  // model AABB in local space                 — model.cpp:13-18
+	int32_t first_surface, n_surfaces;
+};
+static_assert(sizeof(ModelRec) == 41 * 4, "ModelRec layout");
+
+// ---- per-surface record (model::surface = mesh + material) ----
+struct SurfaceRec {
+	float bmin[3], bmax[3];  // mesh AABB (mesh.cpp:254-261)
+	uint32_t kd_root;        // index of the root KD node
+	uint32_t tri_base;       // global id of the mesh's triangle 0
+};
+
+// ---- material factors (core/material.hpp:11-17); emissive10 = emissive_fac * 10 (renderer.cpp:462) ----
+struct MaterialRec {
+	float albedo[3]; float opacity;
+	float emissive10[3]; float roughness;
+	float metallic; float ior; uint32_t shadow_catcher; uint32_t tex_mask;
+};
+
+struct CameraRec { float origin[3]; float basis[9]; float fov; float tan_half_fov; };
+struct SunRec { float basis[9]; float energy[3]; float angular_radius; uint32_t present; };
+
+// ---- host-side container ----
+struct FlatScene {
+	// description as loaded (kept for inspection / tests)
+	std::vector<std::string> model_names;
+	std::vector<float> model_xform;      // [n][12]
+	std::vector<int32_t> model_surf;     // [n][2]
+	std::vector<int32_t> surf_range;     // [ns][8]: v0,nv,t0,nt,kd_root,n_nodes,ref0,n_refs
+	std::vector<float> vertices;         // [nv][11]
+	std::vector<uint32_t> triangles;     // [nt][3] mesh-local ids
+	std::vector<float> materials_raw;    // [ns][11]
+	std::vector<uint8_t> material_tex;   // [ns][7]
+	// derived, device-ready
+	std::vector<ModelRec> models;
+	std::vector<SurfaceRec> surfaces;
+	std::vector<MaterialRec> materials;
+	std::vector<KdNode> kd_nodes;
+	std::vector<uint32_t> kd_refs;       // global triangle ids
+	std::vector<TriRec> tris;
+	std::vector<VertAttr> vattr;
+	CameraRec camera{};
+	SunRec sun{};
+	uint32_t kd_max_depth = 0;
+	bool any_texture = false;
+
+	size_t geometry_bytes() const { return kd_nodes.size() * 8 + kd_refs.size() * 4 + tris.size() * 48; }
+};
+
+// Builds everything derived (AABBs, KD-trees, records) from the "as loaded" arrays + camera/sun floats.
+// camera13: origin(3) basis(9) fov ; sun13: basis(9) energy(3) angular_radius or nullptr.
+void finalize_scene(FlatScene& s, const float* camera13, const float* sun13);
+
+// glTF loader (throws ptx::Error)
+struct Error {
+	int code;
+	std::string msg;
+};
+void load_gltf(const std::string& path, uint32_t camera_index, uint32_t sun_light_index, FlatScene& out);
+
+}  // namespace ptx

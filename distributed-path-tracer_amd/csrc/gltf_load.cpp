@@ -1,0 +1,459 @@
+// glTF 2.0 scene loader producing the flat "as loaded" arrays of ptx::FlatScene.
+//
+// Behavioural contract = the reference loader, core::renderer::load_gltf and friends
+// (LIB/core/renderer.cpp:61-331), including the parts that change pixels:
+//   * node transforms come from TRS only, a node `matrix` is ignored (renderer.cpp:113-128);
+//   * an entity is named after its camera / light when it has one (renderer.cpp:106-111) and the
+//     camera / sun light are found by NAME match against cameras[camera_index] / lights[sun_index];
+//   * root entities live in a std::unordered_map<string, entity> (renderer.hpp:25): a repeated root
+//     name replaces the earlier entity and the visit order of renderer::intersect (renderer.cpp:646-658)
+//     is the container's hash order pushed on a stack — reproduced with the same container type;
+//   * TANGENT (VEC4) is unpacked as count*3 floats of the packed xyzw stream and read back with
+//     stride 3 (renderer.cpp:215-218,248-250; cgltf writes whole elements only) — quirk Q1;
+//   * only scenes[0] is read; materials: factors + which textures are present (renderer.cpp:265-331).
+// The JSON reader below is a small recursive-descent parser written for this file (the reference
+// vendors cgltf; nothing of it is used here). Numbers are converted like cgltf does: (float)strtod().
+#include "flat_scene.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <unordered_map>
+
+namespace ptx {
+namespace {
+
+[[noreturn]] void fail(int code, const std::string& m) { throw Error{code, m}; }
+constexpr int E_IO = 2, E_PARSE = 3, E_NO_CAMERA = 4;
+
+// ------------------------------------------------------------------------------------------- JSON
+struct JVal {
+	enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+	bool b = false;
+	double num = 0;
+	std::string str;
+	std::vector<JVal> arr;
+	std::vector<std::pair<std::string, JVal>> obj;  // insertion order is kept (attribute order matters)
+
+	const JVal* find(const char* key) const {
+		if (kind != Obj) return nullptr;
+		for (auto& kv : obj) if (kv.first == key) return &kv.second;
+		return nullptr;
+	}
+	bool has(const char* key) const { return find(key) != nullptr; }
+	const JVal& at(const char* key) const {
+		const JVal* v = find(key);
+		if (!v) fail(E_PARSE, std::string("glTF: missing key '") + key + "'");
+		return *v;
+	}
+	const JVal& el(size_t i) const {
+		if (kind != Arr || i >= arr.size()) fail(E_PARSE, "glTF: array index out of range");
+		return arr[i];
+	}
+	size_t size() const { return kind == Arr ? arr.size() : 0; }
+	float f() const { if (kind != Num) fail(E_PARSE, "glTF: number expected"); return (float)num; }
+	int64_t i() const { if (kind != Num) fail(E_PARSE, "glTF: integer expected"); return (int64_t)num; }
+	const std::string& s() const { if (kind != Str) fail(E_PARSE, "glTF: string expected"); return str; }
+};
+
+class JsonReader {
+public:
+	explicit JsonReader(const std::string& t) : p_(t.data()), end_(t.data() + t.size()) {}
+	JVal parse() {
+		JVal v = value();
+		ws();
+		if (p_ != end_) fail(E_PARSE, "JSON: trailing characters");
+		return v;
+	}
+private:
+	const char* p_;
+	const char* end_;
+	void ws() { while (p_ < end_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\t' || *p_ == '\r')) p_++; }
+	char peek() { ws(); if (p_ >= end_) fail(E_PARSE, "JSON: unexpected end"); return *p_; }
+	void expect(char c) { if (peek() != c) fail(E_PARSE, std::string("JSON: expected '") + c + "'"); p_++; }
+	JVal value() {
+		char c = peek();
+		JVal v;
+		if (c == '{') {
+			v.kind = JVal::Obj; p_++;
+			if (peek() == '}') { p_++; return v; }
+			for (;;) {
+				std::string k = string();
+				expect(':');
+				v.obj.emplace_back(std::move(k), value());
+				if (peek() == ',') { p_++; continue; }
+				expect('}');
+				return v;
+			}
+		}
+		if (c == '[') {
+			v.kind = JVal::Arr; p_++;
+			if (peek() == ']') { p_++; return v; }
+			for (;;) {
+				v.arr.push_back(value());
+				if (peek() == ',') { p_++; continue; }
+				expect(']');
+				return v;
+			}
+		}
+		if (c == '"') { v.kind = JVal::Str; v.str = string(); return v; }
+		if (!strncmp(p_, "true", 4) && end_ - p_ >= 4) { p_ += 4; v.kind = JVal::Bool; v.b = true; return v; }
+		if (!strncmp(p_, "false", 5) && end_ - p_ >= 5) { p_ += 5; v.kind = JVal::Bool; return v; }
+		if (!strncmp(p_, "null", 4) && end_ - p_ >= 4) { p_ += 4; return v; }
+		// number: hand the token to strtod (cgltf: CGLTF_ATOF on a copy of the token)
+		const char* q = p_;
+		while (q < end_ && (strchr("+-.eE", *q) || (*q >= '0' && *q <= '9'))) q++;
+		if (q == p_) fail(E_PARSE, "JSON: unexpected character");
+		std::string tok(p_, q);
+		v.kind = JVal::Num;
+		v.num = strtod(tok.c_str(), nullptr);
+		p_ = q;
+		return v;
+	}
+	std::string string() {
+		expect('"');
+		std::string out;
+		while (p_ < end_ && *p_ != '"') {
+			if (*p_ == '\\' && p_ + 1 < end_) {
+				p_++;
+				switch (*p_) {
+				case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break;
+				case 'b': out += '\b'; break; case 'f': out += '\f'; break;
+				case 'u': {  // BMP code point -> UTF-8
+					if (end_ - p_ < 5) fail(E_PARSE, "JSON: bad \\u escape");
+					unsigned cp = (unsigned)strtoul(std::string(p_ + 1, p_ + 5).c_str(), nullptr, 16);
+					p_ += 4;
+					if (cp < 0x80) out += (char)cp;
+					else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+					else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+					break;
+				}
+				default: out += *p_;
+				}
+				p_++;
+			} else out += *p_++;
+		}
+		if (p_ >= end_) fail(E_PARSE, "JSON: unterminated string");
+		p_++;
+		return out;
+	}
+};
+
+std::string read_file(const std::string& path, bool binary) {
+	std::ifstream f(path, binary ? std::ios::binary : std::ios::in);
+	if (!f) fail(E_IO, "cannot open '" + path + "'");
+	return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+std::string dir_of(const std::string& path) {
+	size_t k = path.find_last_of('/');
+	return k == std::string::npos ? std::string(".") : path.substr(0, k);
+}
+std::string uri_decode_spaces(std::string s) {  // renderer.cpp:40 does this for textures; buffers go through cgltf, which decodes too
+	size_t k;
+	while ((k = s.find("%20")) != std::string::npos) s.replace(k, 3, " ");
+	return s;
+}
+
+// ------------------------------------------------------------------------------------------- accessors
+struct Gltf {
+	JVal root;
+	std::string dir;
+	std::vector<std::string> buffers;
+	const std::string& buffer(size_t i) {
+		if (i >= buffers.size()) fail(E_PARSE, "glTF: buffer index out of range");
+		if (buffers[i].empty()) {
+			const JVal& b = root.at("buffers").el(i);
+			if (!b.has("uri")) fail(E_PARSE, "glTF: buffer without uri (GLB / embedded buffers are not loaded by the reference either)");
+			buffers[i] = read_file(dir + "/" + uri_decode_spaces(b.at("uri").s()), true);
+		}
+		return buffers[i];
+	}
+};
+
+int n_components(const std::string& t) {
+	if (t == "SCALAR") return 1; if (t == "VEC2") return 2; if (t == "VEC3") return 3; if (t == "VEC4") return 4;
+	if (t == "MAT2") return 4; if (t == "MAT3") return 9; if (t == "MAT4") return 16;
+	fail(E_PARSE, "glTF: unknown accessor type " + t);
+}
+int component_size(int64_t ct) {
+	switch (ct) { case 5120: case 5121: return 1; case 5122: case 5123: return 2; case 5125: case 5126: return 4; }
+	fail(E_PARSE, "glTF: unknown componentType");
+}
+
+struct AccessorView { const uint8_t* base; size_t stride; size_t count; int64_t ctype; int ncomp; bool normalized; };
+
+AccessorView view(Gltf& g, size_t idx) {
+	const JVal& a = g.root.at("accessors").el(idx);
+	if (!a.has("bufferView")) fail(E_PARSE, "glTF: accessor without bufferView (sparse accessors unsupported)");
+	const JVal& bv = g.root.at("bufferViews").el((size_t)a.at("bufferView").i());
+	AccessorView v;
+	v.ctype = a.at("componentType").i();
+	v.ncomp = n_components(a.at("type").s());
+	v.count = (size_t)a.at("count").i();
+	v.normalized = a.has("normalized") && a.at("normalized").b;
+	size_t off = (bv.has("byteOffset") ? (size_t)bv.at("byteOffset").i() : 0) + (a.has("byteOffset") ? (size_t)a.at("byteOffset").i() : 0);
+	size_t elem = (size_t)component_size(v.ctype) * v.ncomp;
+	v.stride = bv.has("byteStride") && bv.at("byteStride").i() > 0 ? (size_t)bv.at("byteStride").i() : elem;
+	const std::string& buf = g.buffer((size_t)bv.at("buffer").i());
+	if (v.count && off + (v.count - 1) * v.stride + elem > buf.size()) fail(E_PARSE, "glTF: accessor exceeds its buffer");
+	v.base = (const uint8_t*)buf.data() + off;
+	return v;
+}
+
+float component_as_float(const uint8_t* p, int64_t ctype, bool normalized) {
+	switch (ctype) {
+	case 5126: { float f; memcpy(&f, p, 4); return f; }
+	case 5125: { uint32_t u; memcpy(&u, p, 4); return (float)u; }
+	case 5123: { uint16_t u; memcpy(&u, p, 2); return normalized ? u / 65535.0f : (float)u; }
+	case 5122: { int16_t i; memcpy(&i, p, 2); float f = normalized ? i / 32767.0f : (float)i; return normalized && f < -1 ? -1.0f : f; }
+	case 5121: { uint8_t u = *p; return normalized ? u / 255.0f : (float)u; }
+	default: { int8_t i = (int8_t)*p; float f = normalized ? i / 127.0f : (float)i; return normalized && f < -1 ? -1.0f : f; }
+	}
+}
+
+// Semantics of cgltf_accessor_unpack_floats(accessor, out, float_count): whole elements only.
+std::vector<float> unpack_floats(Gltf& g, size_t idx, size_t float_count) {
+	AccessorView v = view(g, idx);
+	size_t avail = v.count * v.ncomp;
+	float_count = std::min(avail, float_count);
+	size_t n_el = float_count / v.ncomp;
+	std::vector<float> out(n_el * v.ncomp);
+	int cs = component_size(v.ctype);
+	for (size_t e = 0; e < n_el; e++)
+		for (int c = 0; c < v.ncomp; c++) out[e * v.ncomp + c] = component_as_float(v.base + e * v.stride + (size_t)c * cs, v.ctype, v.normalized);
+	return out;
+}
+std::vector<uint32_t> unpack_indices(Gltf& g, size_t idx) {
+	AccessorView v = view(g, idx);
+	std::vector<uint32_t> out(v.count);
+	for (size_t e = 0; e < v.count; e++) {
+		const uint8_t* p = v.base + e * v.stride;
+		switch (v.ctype) {
+		case 5121: out[e] = *p; break;
+		case 5123: { uint16_t u; memcpy(&u, p, 2); out[e] = u; break; }
+		case 5125: { uint32_t u; memcpy(&u, p, 4); out[e] = u; break; }
+		default: fail(E_PARSE, "glTF: index accessor must be unsigned");
+		}
+	}
+	return out;
+}
+
+// ------------------------------------------------------------------------------------------- entities
+struct Xf { float o[3]; float b[9]; };  // origin + basis columns
+
+Xf compose(const Xf& p, const Xf& c) {  // transform::operator*, LIB/scene/transform.cpp:110-115
+	Xf r;
+	for (int k = 0; k < 3; k++) r.o[k] = (p.b[k] * c.o[0] + p.b[3 + k] * c.o[1] + p.b[6 + k] * c.o[2]) + p.o[k];
+	for (int col = 0; col < 3; col++)   // mat3*mat3: x*rhs.col.x + y*rhs.col.y + z*rhs.col.z (mat3.inl:144-152)
+		for (int k = 0; k < 3; k++)
+			r.b[3 * col + k] = p.b[k] * c.b[3 * col] + p.b[3 + k] * c.b[3 * col + 1] + p.b[6 + k] * c.b[3 * col + 2];
+	return r;
+}
+
+struct Prim { std::vector<float> verts; std::vector<uint32_t> tris; float mat[11]; uint8_t tex[7]; };
+struct Entity {
+	std::string name;
+	Xf local;
+	Entity* parent = nullptr;
+	std::vector<Entity*> children;
+	bool is_model = false;
+	std::vector<Prim> prims;
+};
+
+struct Loader {
+	Gltf g;
+	std::vector<std::unique_ptr<Entity>> pool;
+	std::string camera_name, sun_name;
+	bool want_sun = false;
+	Entity* camera = nullptr;
+	Entity* sun = nullptr;
+	const JVal* lights = nullptr;
+
+	Prim load_prim(const JVal& p) {
+		Prim out{};
+		std::vector<float> pos, uv, nrm, tan;
+		const JVal& attrs = p.at("attributes");
+		for (auto& kv : attrs.obj) {  // JSON order: a later TEXCOORD_n overwrites an earlier one (renderer.cpp:205-208)
+			size_t acc = (size_t)kv.second.i();
+			size_t cnt = (size_t)g.root.at("accessors").el(acc).at("count").i();
+			const std::string& nm = kv.first;
+			if (nm == "POSITION") pos = unpack_floats(g, acc, cnt * 3);
+			else if (nm.rfind("TEXCOORD", 0) == 0) uv = unpack_floats(g, acc, cnt * 2);
+			else if (nm == "NORMAL") nrm = unpack_floats(g, acc, cnt * 3);
+			else if (nm == "TANGENT") { tan = unpack_floats(g, acc, cnt * 3); tan.resize(cnt * 3, 0.0f); }  // Q1
+		}
+		if (!p.has("indices")) fail(E_PARSE, "glTF: non-indexed primitive (the reference dereferences a null accessor here)");
+		std::vector<uint32_t> idx = unpack_indices(g, (size_t)p.at("indices").i());
+		size_t nv = pos.size() / 3, nt = idx.size() / 3;
+		out.verts.assign(nv * 11, 0.0f);
+		for (size_t k = 0; k < nv; k++) {
+			float* v = &out.verts[11 * k];
+			memcpy(v, &pos[3 * k], 12);
+			if (uv.size() >= 2 * (k + 1)) memcpy(v + 3, &uv[2 * k], 8);
+			if (nrm.size() >= 3 * (k + 1)) memcpy(v + 5, &nrm[3 * k], 12);
+			if (tan.size() >= 3 * (k + 1)) memcpy(v + 8, &tan[3 * k], 12);
+		}
+		out.tris.assign(idx.begin(), idx.begin() + nt * 3);
+		for (uint32_t i : out.tris) if (i >= nv) fail(E_PARSE, "glTF: vertex index out of range");
+
+		// material — renderer.cpp:265-331; defaults of core::material (material.hpp:11-17) when absent
+		float m[11] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1.33F, 0};
+		uint8_t tx[7] = {0, 0, 0, 0, 0, 0, 0};
+		if (p.has("material")) {
+			const JVal& mat = g.root.at("materials").el((size_t)p.at("material").i());
+			float bc[4] = {1, 1, 1, 1}, em[3] = {0, 0, 0}, rough = 1, metal = 1;
+			bool alb_tex = false, mr_tex = false;
+			if (const JVal* pbr = mat.find("pbrMetallicRoughness")) {
+				if (const JVal* f = pbr->find("baseColorFactor")) for (int k = 0; k < 4; k++) bc[k] = f->el(k).f();
+				if (const JVal* f = pbr->find("roughnessFactor")) rough = f->f();
+				if (const JVal* f = pbr->find("metallicFactor")) metal = f->f();
+				alb_tex = pbr->has("baseColorTexture");
+				mr_tex = pbr->has("metallicRoughnessTexture");
+			}
+			if (const JVal* f = mat.find("emissiveFactor")) for (int k = 0; k < 3; k++) em[k] = f->el(k).f();
+			std::string name = mat.has("name") ? mat.at("name").s() : "";
+			bool opaque = !mat.has("alphaMode") || mat.at("alphaMode").s() == "OPAQUE";
+			float mm[11] = {bc[0], bc[1], bc[2], bc[3], rough, metal, em[0], em[1], em[2], 1.33F,
+			                (name.find("shadow") != std::string::npos && name.find("catcher") != std::string::npos) ? 1.0f : 0.0f};
+			memcpy(m, mm, sizeof m);
+			uint8_t tt[7] = {(uint8_t)mat.has("normalTexture"), (uint8_t)alb_tex, (uint8_t)(alb_tex && !opaque),
+			                 (uint8_t)mat.has("occlusionTexture"), (uint8_t)mr_tex, (uint8_t)mr_tex, (uint8_t)mat.has("emissiveTexture")};
+			memcpy(tx, tt, sizeof tx);
+		}
+		memcpy(out.mat, m, sizeof m);
+		memcpy(out.tex, tx, sizeof tx);
+		return out;
+	}
+
+	Entity* process_node(size_t ni, Entity* parent) {  // renderer.cpp:101-174
+		const JVal& n = g.root.at("nodes").el(ni);
+		pool.emplace_back(new Entity);
+		Entity* e = pool.back().get();
+		const JVal* light_ref = nullptr;
+		if (const JVal* ext = n.find("extensions"))
+			if (const JVal* kl = ext->find("KHR_lights_punctual")) light_ref = kl->find("light");
+		auto name_of = [](const JVal& o) { return o.has("name") ? o.at("name").s() : std::string(); };
+		if (n.has("camera")) e->name = name_of(g.root.at("cameras").el((size_t)n.at("camera").i()));
+		else if (light_ref && lights) e->name = name_of(lights->el((size_t)light_ref->i()));
+		else e->name = name_of(n);
+
+		float q[4] = {0, 0, 0, 0};  // w, x, y, z — math::quat() is all-zero, which to_basis() maps to identity
+		if (const JVal* r = n.find("rotation")) { q[0] = r->el(3).f(); q[1] = r->el(0).f(); q[2] = r->el(1).f(); q[3] = r->el(2).f(); }
+		float sc[3] = {1, 1, 1}, tr[3] = {0, 0, 0};
+		if (const JVal* s = n.find("scale")) for (int k = 0; k < 3; k++) sc[k] = s->el(k).f();
+		if (const JVal* t = n.find("translation")) for (int k = 0; k < 3; k++) tr[k] = t->el(k).f();
+		const float w = q[0], x = q[1], y = q[2], z = q[3];
+		float b[9] = {1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w),      // quat::to_basis, quat.cpp:95-113
+		              2 * (x * y - z * w), 1 - 2 * (x * x + z * z), 2 * (y * z + x * w),
+		              2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)};
+		for (int c = 0; c < 3; c++) for (int k = 0; k < 3; k++) e->local.b[3 * c + k] = b[3 * c + k] * sc[c];  // make_basis
+		memcpy(e->local.o, tr, 12);
+
+		if (n.has("mesh")) {
+			e->is_model = true;
+			const JVal& prims = g.root.at("meshes").el((size_t)n.at("mesh").i()).at("primitives");
+			for (size_t k = 0; k < prims.size(); k++) e->prims.push_back(load_prim(prims.el(k)));
+		}
+		if (e->name == camera_name) camera = e;            // pre-order; the last match wins (renderer.cpp:145-152)
+		if (want_sun && e->name == sun_name) sun = e;
+		if (const JVal* ch = n.find("children"))
+			for (size_t k = 0; k < ch->size(); k++) {
+				Entity* c = process_node((size_t)ch->el(k).i(), e);
+				c->parent = e;
+				e->children.push_back(c);
+			}
+		(void)parent;
+		return e;
+	}
+
+	static Xf global_of(const Entity* e) {  // entity::get_global_transform, LIB/scene/entity.cpp:72-85
+		return e->parent ? compose(global_of(e->parent), e->local) : e->local;
+	}
+};
+
+}  // namespace
+
+void load_gltf(const std::string& path, uint32_t camera_index, uint32_t sun_light_index, FlatScene& out) {
+	Loader L;
+	L.g.root = JsonReader(read_file(path, false)).parse();
+	L.g.dir = dir_of(path);
+	L.g.buffers.resize(L.g.root.has("buffers") ? L.g.root.at("buffers").size() : 0);
+
+	const JVal* cams = L.g.root.find("cameras");
+	if (!cams || cams->size() < (size_t)camera_index + 1)
+		fail(E_NO_CAMERA, "Scene does not contain camera #" + std::to_string(camera_index) + ".");
+	const JVal& cam = cams->el(camera_index);
+	L.camera_name = cam.has("name") ? cam.at("name").s() : std::string();
+	const JVal* sun_def = nullptr;
+	if (const JVal* ext = L.g.root.find("extensions"))
+		if (const JVal* kl = ext->find("KHR_lights_punctual")) L.lights = kl->find("lights");
+	if (sun_light_index != 0xFFFFFFFFu && L.lights && L.lights->size() >= (size_t)sun_light_index + 1) {
+		const JVal& l = L.lights->el(sun_light_index);
+		if (l.has("type") && l.at("type").s() == "directional") {  // renderer.cpp:84-90
+			sun_def = &l;
+			L.want_sun = true;
+			L.sun_name = l.has("name") ? l.at("name").s() : std::string();
+		}
+	}
+
+	const JVal& scene_nodes = L.g.root.at("scenes").el(0).at("nodes");  // data->scenes[0], renderer.cpp:71
+	std::vector<Entity*> roots;
+	for (size_t k = 0; k < scene_nodes.size(); k++) roots.push_back(L.process_node((size_t)scene_nodes.el(k).i(), nullptr));
+	if (!L.camera) fail(E_NO_CAMERA, "Scene is missing a camera.");
+
+	// entities[name] = entity (renderer.cpp:171), then the DFS of renderer::intersect (renderer.cpp:646-671)
+	std::unordered_map<std::string, Entity*> by_name;
+	for (Entity* e : roots) by_name[e->name] = e;
+	std::vector<Entity*> stack, visit;
+	for (auto& kv : by_name) stack.push_back(kv.second);
+	while (!stack.empty()) {
+		Entity* e = stack.back();
+		stack.pop_back();
+		for (Entity* c : e->children) stack.push_back(c);
+		if (e->is_model) visit.push_back(e);
+	}
+
+	out = FlatScene{};
+	int32_t ns = 0, nv = 0, nt = 0;
+	for (Entity* e : visit) {
+		Xf gx = Loader::global_of(e);
+		out.model_names.push_back(e->name);
+		out.model_xform.insert(out.model_xform.end(), gx.o, gx.o + 3);
+		out.model_xform.insert(out.model_xform.end(), gx.b, gx.b + 9);
+		out.model_surf.push_back(ns);
+		out.model_surf.push_back((int32_t)e->prims.size());
+		for (Prim& p : e->prims) {
+			int32_t pv = (int32_t)(p.verts.size() / 11), pt = (int32_t)(p.tris.size() / 3);
+			int32_t rg[8] = {nv, pv, nt, pt, 0, 0, 0, 0};
+			out.surf_range.insert(out.surf_range.end(), rg, rg + 8);
+			out.vertices.insert(out.vertices.end(), p.verts.begin(), p.verts.end());
+			out.triangles.insert(out.triangles.end(), p.tris.begin(), p.tris.end());
+			out.materials_raw.insert(out.materials_raw.end(), p.mat, p.mat + 11);
+			out.material_tex.insert(out.material_tex.end(), p.tex, p.tex + 7);
+			nv += pv; nt += pt; ns++;
+		}
+	}
+	Xf cx = Loader::global_of(L.camera);
+	float cam13[13];
+	memcpy(cam13, cx.o, 12);
+	memcpy(cam13 + 3, cx.b, 36);
+	cam13[12] = cam.at("perspective").at("yfov").f();
+	float sun13[13];
+	bool have_sun = L.sun != nullptr && sun_def != nullptr;
+	if (have_sun) {
+		Xf sx = Loader::global_of(L.sun);
+		memcpy(sun13, sx.b, 36);
+		float col[3] = {1, 1, 1}, inten = 1;
+		if (const JVal* c = sun_def->find("color")) for (int k = 0; k < 3; k++) col[k] = c->el(k).f();
+		if (const JVal* i = sun_def->find("intensity")) inten = i->f();
+		for (int k = 0; k < 3; k++) sun13[9 + k] = col[k] * inten;  // renderer.cpp:159
+		sun13[12] = 0.004732f;                                      // sun_light::angular_radius, sun_light.hpp:10
+	}
+	finalize_scene(out, cam13, have_sun ? sun13 : nullptr);
+}
+
+}  // namespace ptx

@@ -1,0 +1,592 @@
+// HIP kernels for gfx950 (MI355X / CDNA4): the ray-intersection + Monte-Carlo shading hot path.
+//
+// Design: one ray per lane, 64-lane waves. A launch is a grid of persistent
+// workgroups (one per CU) that first stage the scene geometry — 8-byte KD nodes, 4-byte leaf
+// references, 48-byte triangle records — into the CU's LDS (it is the only data touched in the
+// traversal inner loops), then each WAVE pulls chunks of camera paths from a global counter and runs
+// them through all bounces by itself: the rays of a chunk live in a wave-private SoA-of-float4 stream
+// in global memory (four coalesced 1-KiB loads per 64 rays), every bounce reads the stream, traces,
+// shades, and writes the survivors back compacted with a wave ballot + lane prefix count, so waves
+// stay full while paths die. No workgroup barrier, no inter-workgroup traffic, no atomics besides one
+// counter fetch per chunk; per-sample radiance leaves through plain stores and a second tiny kernel
+// adds the samples of each pixel in a fixed order (bitwise reproducible, no float atomics).
+//
+// Numerics: IEEE binary32 in the reference's operation order, no FMA contraction (-ffp-contract=off),
+// correctly rounded divide / sqrt, the reference's double-precision islands kept in double. Each device
+// function cites what it restates (paths relative to path-tracer-core/path_tracer_lib/path_tracer/).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace ptx {
+
+#define DEV __device__ __forceinline__
+
+constexpr float kEps = 0.0001f;                        // math::epsilon (math/math.hpp:16)
+constexpr double kPi = 3.14159265358979323846;         // math::pi is double (math/math.hpp:18)
+constexpr double kInvSqrt3 = 1.0 / 1.7320508075688772; // 1 / math::sqrt3 (util/rand_cone_vec.cpp:23)
+
+struct V3 { float x, y, z; };
+DEV V3 mk(float x, float y, float z) { return {x, y, z}; }
+DEV V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+DEV V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+DEV V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+DEV V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+DEV V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+DEV V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+DEV V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                    // math/vec3.inl:236
+DEV V3 cross(V3 l, V3 r) { return {(l.y * r.z) - (l.z * r.y), (l.z * r.x) - (l.x * r.z), (l.x * r.y) - (l.y * r.x)}; }
+DEV float length(V3 a) { return sqrtf(dot(a, a)); }
+DEV V3 normalize(V3 a) { return a * (1.0f / length(a)); }                                  // math/vec3.inl:251
+DEV float pmax(float a, float b) { return b > a ? b : a; }                                 // math::max (NaN-asymmetric), math.inl:169
+DEV float pmin(float a, float b) { return b < a ? b : a; }                                 // math::min, math.inl:179
+DEV float lerpf(float a, float b, float w) { return a + (b - a) * w; }                     // math.inl:164
+DEV float clampf(float x, float lo, float hi) { return pmin(pmax(x, lo), hi); }            // math.inl:154
+DEV V3 lerp3(V3 a, V3 b, float w) { return {lerpf(a.x, b.x, w), lerpf(a.y, b.y, w), lerpf(a.z, b.z, w)}; }
+DEV V3 lerp3(V3 a, V3 b, V3 w) { return {lerpf(a.x, b.x, w.x), lerpf(a.y, b.y, w.y), lerpf(a.z, b.z, w.z)}; }
+DEV V3 reflect3(V3 incident, V3 normal) { return incident - 2 * dot(normal, incident) * normal; }  // core/utils.hpp:38
+// math::pow(float, 5): std::pow promotes to double; x^5 by exact-ish double products, rounded once to float
+DEV float pow5(float x) { double d = (double)x; double d2 = d * d; return (float)(d2 * d2 * d); }
+DEV float sel3(V3 v, uint32_t axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+// column-major 3x3 (float[9] = x.xyz y.xyz z.xyz) times vector: each ROW dotted with v (math/mat3.inl:219-224)
+DEV V3 mulmv(const float* m, V3 v) {
+	return {m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z, m[2] * v.x + m[5] * v.y + m[8] * v.z};
+}
+
+// ------------------------------------------------------------------------------------ geometry access
+// The three traversal arrays, either in LDS (whole scene staged per workgroup) or in global memory.
+struct Geom {
+	const uint2* nodes;
+	const uint32_t* refs;
+	const float4* tris;
+};
+
+// geometry::aabb::intersect — geometry/aabb.cpp:41-67
+DEV bool aabb_test(const float* mn, const float* mx, V3 o, V3 d, float& nr, float& fr) {
+	if (mn[0] > mx[0] || mn[1] > mx[1] || mn[2] > mx[2]) return false;
+	float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+	float ax = (mn[0] - o.x) * ix, ay = (mn[1] - o.y) * iy, az = (mn[2] - o.z) * iz;
+	float bx = (mx[0] - o.x) * ix, by = (mx[1] - o.y) * iy, bz = (mx[2] - o.z) * iz;
+	nr = pmax(pmax(pmin(ax, bx), pmin(ay, by)), pmin(az, bz));
+	fr = pmin(pmin(pmax(ax, bx), pmax(ay, by)), pmax(az, bz));
+	if (nr > fr) return false;
+	return fr >= 0;
+}
+
+// geometry::triangle::intersect — geometry/triangle.cpp:120-190 (Cramer's rule, no culling, +-epsilon slack)
+DEV float tri_test(V3 a, V3 b, V3 c, V3 o, V3 d, float& alpha, float& beta, float& gamma) {
+	V3 mx = a - b, my = a - c, v = a - o;
+	float c1 = my.y * d.z - d.y * my.z;
+	float c2 = mx.y * d.z - d.y * mx.z;
+	float c3 = mx.y * my.z - my.y * mx.z;
+	float c4 = v.y * d.z - d.y * v.z;
+	float c5 = mx.y * v.z - v.y * mx.z;
+	float c6 = my.y * v.z - v.y * my.z;
+	float inv_det = 1.0f / (mx.x * c1 - my.x * c2 + d.x * c3);
+	beta = inv_det * (v.x * c1 - my.x * c4 - d.x * c6);
+	if (beta < 0 - kEps || beta > 1 + kEps) return -1.0f;
+	gamma = inv_det * (mx.x * c4 - v.x * c2 + d.x * c5);
+	if (gamma < 0 - kEps || gamma + beta > 1 + kEps) return -1.0f;
+	float dist = inv_det * (mx.x * c6 - my.x * c5 + v.x * c3);
+	alpha = 1 - beta - gamma;
+	return dist;
+}
+
+struct MeshHit { float t; float b0, b1, b2; uint32_t tri; };
+
+constexpr int kStack = 32;  // >= reference max depth 25 (+1): one push per level at most
+
+// core::mesh::intersect — core/mesh.cpp:300-405: front-to-back stack traversal, returns at the first
+// leaf that yields a hit within [.., max_dist].
+DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, MeshHit& out, uint32_t* stk_node, float* stk_min,
+                       float* stk_max) {
+	float nr, fr;
+	if (!aabb_test(sf.bmin, sf.bmax, o, d, nr, fr)) return false;
+	int sp = 0;
+	uint32_t node = sf.kd_root;
+	float min_dist = nr, max_dist = fr;
+	bool have = true;  // a node to descend from
+	for (;;) {
+		if (!have) {
+			if (sp == 0) return false;
+			sp--;
+			node = stk_node[sp]; min_dist = stk_min[sp]; max_dist = stk_max[sp];
+		}
+		have = false;
+		// descend to a leaf (or off the tree through a missing child)
+		bool valid = true;
+		uint2 nd = g.nodes[node];
+		while ((nd.y & 3u) != KD_LEAF) {
+			uint32_t axis = nd.y & 3u;
+			float split = __uint_as_float(nd.x);
+			float oa = sel3(o, axis), da = sel3(d, axis);
+			float split_dist = (split - oa) / da;
+			bool has_l = nd.y & 4u, has_r = nd.y & 8u;
+			uint32_t li = nd.y >> 4, ri = li + (has_l ? 1u : 0u);
+			bool left_first = oa < split;
+			uint32_t first = left_first ? li : ri, second = left_first ? ri : li;
+			bool has_first = left_first ? has_l : has_r, has_second = left_first ? has_r : has_l;
+			uint32_t next;
+			bool has_next;
+			if (split_dist < 0 || split_dist > max_dist) { next = first; has_next = has_first; }
+			else if (split_dist < min_dist) { next = second; has_next = has_second; }
+			else {
+				if (has_second && sp < kStack) { stk_node[sp] = second; stk_min[sp] = split_dist; stk_max[sp] = max_dist; sp++; }
+				next = first; has_next = has_first;
+				max_dist = split_dist;
+			}
+			if (!has_next) { valid = false; break; }
+			node = next;
+			nd = g.nodes[node];
+		}
+		if (!valid) continue;
+		// leaf: nearest triangle with t <= max_dist; ties keep the first (mesh.cpp:381-389)
+		uint32_t first_ref = nd.x, count = nd.y >> 2;
+		float best_t = -1.0f, bb0 = 0, bb1 = 0, bb2 = 0;
+		uint32_t best_tri = 0;
+		for (uint32_t i = 0; i < count; i++) {
+			uint32_t ti = g.refs[first_ref + i];
+			float4 A = g.tris[3 * ti], B = g.tris[3 * ti + 1], C = g.tris[3 * ti + 2];
+			float al, be, ga;
+			float t = tri_test(mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), mk(C.x, C.y, C.z), o, d, al, be, ga);
+			if (t >= 0 && t <= max_dist && (t < best_t || !(best_t >= 0))) { best_t = t; bb0 = al; bb1 = be; bb2 = ga; best_tri = ti; }
+		}
+		if (!(best_t >= 0)) continue;
+		out.t = best_t; out.b0 = bb0; out.b1 = bb1; out.b2 = bb2; out.tri = best_tri;
+		return true;
+	}
+}
+
+struct SceneHit { float dist; int model; int surface; uint32_t tri; float b0, b1, b2; };
+
+// renderer::intersect (core/renderer.cpp:645-671) over scene::model::intersect (scene/model.cpp:20-72)
+DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& best, uint32_t* stk_node, float* stk_min,
+                        float* stk_max) {
+	best.dist = -1.0f;
+	best.model = -1;
+	for (int m = 0; m < S.n_models; m++) {
+		const ModelRec& M = S.models[m];
+		// ray::transform(inverse): origin' = inv*o, dir' = normalize(inv.basis*dir)  (geometry/ray.cpp:10-15)
+		V3 lo = mulmv(M.inv_basis, o) + mk(M.inv_origin[0], M.inv_origin[1], M.inv_origin[2]);
+		V3 ld = normalize(mulmv(M.inv_basis, d));
+		float nr, fr;
+		if (!aabb_test(M.bmin, M.bmax, lo, ld, nr, fr)) continue;
+		MeshHit nearest;
+		nearest.t = -1.0f;
+		int hit_surface = -1;
+		for (int s = 0; s < M.n_surfaces; s++) {
+			MeshHit h;
+			if (!mesh_traverse(g, S.surfaces[M.first_surface + s], lo, ld, h, stk_node, stk_min, stk_max)) continue;
+			if (h.t < nearest.t || !(nearest.t >= 0)) { nearest = h; hit_surface = M.first_surface + s; }
+		}
+		if (!(nearest.t >= 0)) continue;
+		// local -> world distance (model.cpp:62-63)
+		float wd = length(mulmv(M.basis, ld * nearest.t));
+		if (!(wd >= 0)) continue;
+		if (wd < best.dist || !(best.dist >= 0)) {
+			best.dist = wd; best.model = m; best.surface = hit_surface; best.tri = nearest.tri;
+			best.b0 = nearest.b0; best.b1 = nearest.b1; best.b2 = nearest.b2;
+		}
+	}
+	return best.model >= 0;
+}
+
+struct Surf { V3 pos, nrm, tan; float u, v; };
+
+// attribute interpolation of renderer::intersect — core/renderer.cpp:688-715
+DEV void hit_attributes(const DevScene& S, const Geom& g, const SceneHit& h, Surf& out) {
+	const ModelRec& M = S.models[h.model];
+	float4 A = g.tris[3 * h.tri], B = g.tris[3 * h.tri + 1], C = g.tris[3 * h.tri + 2];
+	uint32_t ia = __float_as_uint(A.w), ib = __float_as_uint(B.w), ic = __float_as_uint(C.w);
+	float4 a0 = S.vattr[2 * ia], a1 = S.vattr[2 * ia + 1];
+	float4 b0 = S.vattr[2 * ib], b1 = S.vattr[2 * ib + 1];
+	float4 c0 = S.vattr[2 * ic], c1 = S.vattr[2 * ic + 1];
+	V3 lp = mk(A.x, A.y, A.z) * h.b0 + mk(B.x, B.y, B.z) * h.b1 + mk(C.x, C.y, C.z) * h.b2;
+	out.pos = mulmv(M.basis, lp) + mk(M.origin[0], M.origin[1], M.origin[2]);
+	out.u = a0.w * h.b0 + b0.w * h.b1 + c0.w * h.b2;
+	out.v = a1.w * h.b0 + b1.w * h.b1 + c1.w * h.b2;
+	out.nrm = normalize(mulmv(M.nmat, mk(a0.x, a0.y, a0.z) * h.b0 + mk(b0.x, b0.y, b0.z) * h.b1 + mk(c0.x, c0.y, c0.z) * h.b2));
+	out.tan = normalize(mulmv(M.nmat, mk(a1.x, a1.y, a1.z) * h.b0 + mk(b1.x, b1.y, b1.z) * h.b1 + mk(c1.x, c1.y, c1.z) * h.b2));
+}
+
+// intersect_result::get_normal (renderer.cpp:430-435) with material::get_normal = (0,0,1) (no normal map)
+DEV V3 shading_normal(const Surf& s) {
+	V3 bin = cross(s.nrm, s.tan);
+	return {s.tan.x * 0.0f + bin.x * 0.0f + s.nrm.x * 1.0f, s.tan.y * 0.0f + bin.y * 0.0f + s.nrm.y * 1.0f,
+	        s.tan.z * 0.0f + bin.z * 0.0f + s.nrm.z * 1.0f};
+}
+
+// ------------------------------------------------------------------------------------ sampling / BSDF
+// util::rand_cone_vec — util/rand_cone_vec.cpp:8-35
+DEV V3 rand_cone_vec(float rnd, float cos_theta, V3 normal) {
+	float phi = (float)((double)(rnd * 2) * kPi);
+	float sin_theta = sqrtf(1 - cos_theta * cos_theta);
+	V3 cone = {cosf(phi) * sin_theta, sinf(phi) * sin_theta, cos_theta};
+	V3 np = {0, 0, 0};
+	if ((double)fabsf(normal.x) < kInvSqrt3) np.x = 1;
+	else if ((double)fabsf(normal.y) < kInvSqrt3) np.y = 1;
+	else np.z = 1;
+	V3 tangent = normalize(cross(normal, np));
+	V3 binormal = cross(normal, tangent);
+	return {tangent.x * cone.x + binormal.x * cone.y + normal.x * cone.z, tangent.y * cone.x + binormal.y * cone.y + normal.y * cone.z,
+	        tangent.z * cone.x + binormal.z * cone.y + normal.z * cone.z};
+}
+DEV float fresnel_schlick(V3 outcoming, V3 incoming, float ior) {  // core/pbr.cpp:13-25
+	V3 halfway = normalize(outcoming + incoming);
+	float cos_theta = dot(outcoming, halfway);
+	float f0 = (ior - 1) / (ior + 1);
+	f0 *= f0;
+	return lerpf(f0, 1, pow5(1 - cos_theta));
+}
+DEV V3 importance_diffuse(float u1, float u2, V3 normal) {  // core/pbr.cpp:71-77
+	float theta = acosf(2 * u1 - 1) * 0.5F;
+	return rand_cone_vec(u2, cosf(theta), normal);
+}
+DEV V3 importance_specular(float u1, float u2, V3 normal, V3 outcoming, float roughness) {  // core/pbr.cpp:79-91
+	roughness *= roughness;
+	roughness *= roughness;
+	float cos_theta = sqrtf((1 - u1) / (1 + (roughness - 1) * u1));
+	V3 halfway = rand_cone_vec(u2, cos_theta, normal);
+	return reflect3(-outcoming, halfway);
+}
+DEV float smith_g1(V3 n, V3 l, float k) { float c = dot(n, l); return c / pmax(lerpf(k, 1, c), kEps); }  // pbr.cpp:95-102
+DEV float pdf_diffuse(V3 n, V3 i) { return (float)((double)dot(n, i) / kPi); }                           // pbr.cpp:118-123
+DEV float pdf_specular(V3 n, V3 o, V3 i, float roughness) {  // core/pbr.cpp:172-184 (+ distribution_ggx :125-140, geometry_smith :104-114)
+	float r4 = roughness * roughness;
+	r4 *= r4;
+	V3 halfway = normalize(o + i);
+	float cos_phi = dot(n, halfway);
+	float denom = 1 + (r4 - 1) * (cos_phi * cos_phi);
+	float cos_theta = dot(n, i);
+	double dd = kPi * (double)denom * (double)denom;
+	double mxd = (double)kEps > dd ? (double)kEps : dd;
+	float dist = (float)((double)(cos_theta * r4) / mxd);
+	float r = roughness + 1;
+	float k = (r * r) / 8;
+	float geo = smith_g1(n, o, k) * smith_g1(n, i, k);
+	float ndo = dot(n, o), ndi = dot(n, i);
+	return (dist * geo) / pmax(4 * ndo * ndi, kEps);
+}
+// BRDF / PDF combination, inline in renderer::trace (core/renderer.cpp:521-556 and :579-606).
+// Returns brdf (rgb); pdf_mix = lerp(pdf_d, pdf_s, specular_probability).
+DEV V3 eval_brdf(V3 n, V3 o, V3 i, V3 albedo, float roughness, float metallic, float spec_prob, float& pdf_mix) {
+	float diffuse_pdf = pdf_diffuse(n, i);
+	V3 diffuse_brdf = diffuse_pdf * albedo;
+	float specular_pdf = pdf_specular(n, o, i, roughness);
+	V3 fr = lerp3(mk(0.04F, 0.04F, 0.04F), albedo, metallic);
+	V3 halfway = normalize(o + i);
+	float cos_theta = dot(o, halfway);
+	fr = lerp3(fr, mk(1, 1, 1), pow5(1 - cos_theta));
+	diffuse_brdf = lerp3(diffuse_brdf, mk(0, 0, 0), metallic);
+	pdf_mix = lerpf(diffuse_pdf, specular_pdf, spec_prob);
+	return lerp3(diffuse_brdf, mk(specular_pdf, specular_pdf, specular_pdf), fr);
+}
+
+// ------------------------------------------------------------------------------------ RNG
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw — SC'11). Replaces core::rand() (core/utils.hpp:8-13).
+DEV uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+	for (int i = 0; i < 10; i++) {
+		uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+		uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+		c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+		k0 += 0x9E3779B9u;
+		k1 += 0xBB67AE85u;
+	}
+	return c;
+}
+DEV float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+enum { BLOCK_SURFACE = 0, BLOCK_SUN = 1, BLOCK_JITTER = 2 };
+DEV float4 draws(const RenderParams& P, uint32_t pixel, uint32_t sample, uint32_t depth, uint32_t pass, uint32_t block) {
+	if (pass > 0xFFFFu) pass = 0xFFFFu;
+	uint4 r = philox4x32_10(make_uint4(pixel, sample, (depth << 16) | pass, block), P.seed_lo, P.seed_hi);
+	return make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
+}
+
+// scene::camera::get_ray — scene/camera.cpp:10-21 ; pixel loop of renderer::render — core/renderer.cpp:359-370
+DEV void camera_ray(const DevScene& S, const RenderParams& P, uint32_t x, uint32_t y, uint32_t sample, V3& o, V3& d) {
+	float4 j = draws(P, y * P.W + x, sample, 0, 0, BLOCK_JITTER);
+	float ndc_x = (((float)x + j.x) / (float)P.W) * 2 - 1;
+	float ndc_y = (((float)y + j.y) / (float)P.H) * 2 - 1;
+	ndc_y = -ndc_y;
+	float ratio = (float)P.W / (float)P.H;
+	float dx = S.cam.tan_half_fov * ndc_x, dy = S.cam.tan_half_fov * ndc_y;
+	dx *= ratio;
+	V3 dir = normalize(mk(dx, dy, -1));
+	// ray.transform(global): origin = basis*0 + origin, dir = normalize(basis*dir)
+	V3 z = {0, 0, 0};
+	o = mulmv(S.cam.basis, z) + mk(S.cam.origin[0], S.cam.origin[1], S.cam.origin[2]);
+	d = normalize(mulmv(S.cam.basis, dir));
+}
+
+// ------------------------------------------------------------------------------------ one path vertex
+// renderer::trace (core/renderer.cpp:437-643) in iterative throughput form (DESIGN.md "Estimator"):
+//   L += T * (direct + emissive);  T *= clamp(brdf / max(pdf, eps), 0, 1);  next ray.
+// Returns true when the path continues with (o, d) updated. `rays` counts renderer::intersect calls.
+DEV bool path_vertex(const DevScene& S, const Geom& g, const RenderParams& P, uint32_t pixel, uint32_t sample, uint32_t depth,
+                     V3& o, V3& d, V3& T, V3& L, uint32_t& rays, uint32_t* stk_node, float* stk_min, float* stk_max) {
+	uint32_t pass = 0;
+	for (;;) {
+		SceneHit h;
+		rays++;
+		if (!scene_traverse(S, g, o, d, h, stk_node, stk_min, stk_max)) {
+			L = L + T * mk(P.env[0], P.env[1], P.env[2]);  // miss: environment_factor (renderer.cpp:443-451)
+			return false;
+		}
+		Surf sf;
+		hit_attributes(S, g, h, sf);
+		const MaterialRec& mt = S.materials[h.surface];
+		V3 albedo = mk(mt.albedo[0], mt.albedo[1], mt.albedo[2]);
+		float roughness = mt.roughness, metallic = mt.metallic, opacity = mt.opacity;
+		float4 rnd = draws(P, pixel, sample, depth, pass, BLOCK_SURFACE);  // x opacity, y lobe, z/w BSDF sample
+
+		bool pass_through = !(opacity == 1.0f || fabsf(opacity - 1.0f) < kEps) && rnd.x > opacity;  // renderer.cpp:466-472
+		V3 normal = mk(0, 0, 0), outcoming = -d;
+		float spec_prob = 0;
+		if (!pass_through) {
+			normal = shading_normal(sf);
+			if (dot(normal, outcoming) <= 0) return false;                  // renderer.cpp:478-479: black, path ends
+			roughness = pmax(roughness, 0.05F);
+			spec_prob = fresnel_schlick(outcoming, reflect3(-outcoming, normal), mt.ior);
+			spec_prob = pmax(spec_prob, metallic);
+		}
+		V3 direct_out = mk(0, 0, 0);
+		if (!pass_through && S.sun.present) {                                // renderer.cpp:498-564
+			float4 sr = draws(P, pixel, sample, depth, pass, BLOCK_SUN);
+			V3 din = mulmv(S.sun.basis, mk(0, 0, 1));
+			din = rand_cone_vec(sr.x, cosf(sr.y * S.sun.angular_radius), din);
+			if (dot(normal, din) > 0) {
+				V3 so = sf.pos + din * kEps, sd = normalize(din);
+				SceneHit sh;
+				rays++;
+				bool shadowed = scene_traverse(S, g, so, sd, sh, stk_node, stk_min, stk_max);
+				bool catcher = mt.shadow_catcher && depth == 0;
+				if (!shadowed) {
+					if (catcher) pass_through = true;                        // lit shadow catcher behaves as fully transparent
+					else {
+						float pdf_unused;
+						V3 brdf = eval_brdf(normal, outcoming, din, albedo, roughness, metallic, spec_prob, pdf_unused);
+						V3 e = mk(S.sun.energy[0], S.sun.energy[1], S.sun.energy[2]);
+						float pdf = lerpf(1.0f, 1.0f, spec_prob);
+						V3 v = brdf * e / pmax(pdf, kEps);
+						direct_out = mk(clampf(v.x, 0, e.x), clampf(v.y, 0, e.y), clampf(v.z, 0, e.z));
+					}
+				} else if (catcher) return false;                            // shadowed catcher: black
+			}
+		}
+		if (pass_through) {
+			o = sf.pos + d * kEps;
+			d = normalize(d);
+			pass++;
+			if (pass > 4096) return false;  // safety bound; the reference would recurse without limit
+			continue;
+		}
+		V3 inc = (rnd.y < spec_prob) ? importance_specular(rnd.z, rnd.w, normal, outcoming, roughness)
+		                              : importance_diffuse(rnd.z, rnd.w, normal);
+		L = L + T * (direct_out + mk(mt.emissive10[0], mt.emissive10[1], mt.emissive10[2]));
+		if (!(dot(normal, inc) > 0)) return false;                           // renderer.cpp:578: no indirect term
+		float pdf;
+		V3 brdf = eval_brdf(normal, outcoming, inc, albedo, roughness, metallic, spec_prob, pdf);
+		float ip = pmax(pdf, kEps);
+		T = T * mk(clampf(brdf.x / ip, 0, 1), clampf(brdf.y / ip, 0, 1), clampf(brdf.z / ip, 0, 1));  // renderer.cpp:617-620
+		o = sf.pos + inc * kEps;
+		d = normalize(inc);
+		return true;
+	}
+}
+
+// ------------------------------------------------------------------------------------ LDS staging
+template <bool LDS>
+DEV Geom stage_geometry(const DevScene& S, unsigned char* smem) {
+	if constexpr (!LDS) return {S.nodes, S.refs, S.tris};
+	else {
+		// [triangle records][KD nodes][leaf refs], each region a multiple of 16 B
+		uint4* dst = reinterpret_cast<uint4*>(smem);
+		const uint32_t n_tri16 = S.n_tris * 3, n_node16 = (S.n_nodes + 1) / 2, n_ref16 = (S.n_refs + 3) / 4;
+		const uint4* src_t = reinterpret_cast<const uint4*>(S.tris);
+		const uint4* src_n = reinterpret_cast<const uint4*>(S.nodes);
+		const uint4* src_r = reinterpret_cast<const uint4*>(S.refs);
+		for (uint32_t i = threadIdx.x; i < n_tri16; i += blockDim.x) dst[i] = src_t[i];
+		for (uint32_t i = threadIdx.x; i < n_node16; i += blockDim.x) dst[n_tri16 + i] = src_n[i];
+		for (uint32_t i = threadIdx.x; i < n_ref16; i += blockDim.x) dst[n_tri16 + n_node16 + i] = src_r[i];
+		__syncthreads();
+		return {reinterpret_cast<const uint2*>(dst + n_tri16), reinterpret_cast<const uint32_t*>(dst + n_tri16 + n_node16),
+		        reinterpret_cast<const float4*>(dst)};
+	}
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
+
+// ------------------------------------------------------------------------------------ integrator kernel
+// One launch = `P.n_paths` camera paths (P.pass_spp samples of every tile pixel), all bounces.
+template <bool LDS>
+__global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S, RenderParams P, PassBuffers B) {
+	const Geom g = stage_geometry<LDS>(S, g_smem);
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave_slot = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	// wave-private ray stream: 2 buffers x 4 float4 arrays x kChunk entries
+	float4* qbase = B.queues + (size_t)wave_slot * (2u * 4u * kChunk);
+	uint32_t stk_node[kStack];
+	float stk_min[kStack], stk_max[kStack];
+	uint32_t rays = 0;
+
+	for (;;) {
+		uint32_t chunk = 0;
+		if (lane == 0) chunk = atomicAdd(B.chunk_counter, 1u);
+		chunk = __builtin_amdgcn_readfirstlane(chunk);
+		const uint64_t first = (uint64_t)chunk * kChunk;
+		if (first >= P.n_paths) break;
+		uint32_t n_in = (uint32_t)((P.n_paths - first) < (uint64_t)kChunk ? (P.n_paths - first) : kChunk);
+
+		for (uint32_t depth = 0; depth < P.bounces && n_in > 0; depth++) {
+			float4* qin = qbase + (size_t)(depth & 1u) * (4u * kChunk);
+			float4* qout = qbase + (size_t)((depth + 1u) & 1u) * (4u * kChunk);
+			const bool last = depth + 1 == P.bounces;
+			uint32_t n_out = 0;
+			for (uint32_t base = 0; base < n_in; base += 64) {
+				const uint32_t i = base + lane;
+				const bool active = i < n_in;
+				V3 o = {0, 0, 0}, d = {0, 0, 1}, T = {1, 1, 1}, L = {0, 0, 0};
+				uint32_t id = 0;
+				if (active) {
+					if (depth == 0) {
+						id = (uint32_t)first + i;  // id within the pass: sample-major, pixel-minor
+					} else {
+						float4 q0 = qin[i], q1 = qin[kChunk + i], q2 = qin[2 * kChunk + i], q3 = qin[3 * kChunk + i];
+						o = mk(q0.x, q0.y, q0.z); id = __float_as_uint(q0.w);
+						d = mk(q1.x, q1.y, q1.z); T = mk(q1.w, q2.x, q2.y);
+						L = mk(q2.z, q2.w, q3.x);
+					}
+				}
+				const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
+				const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
+				const uint32_t pixel = py * P.W + px, sample = P.sample0 + s_local;
+				bool alive = false;
+				if (active) {
+					if (depth == 0) camera_ray(S, P, px, py, sample, o, d);
+					alive = path_vertex(S, g, P, pixel, sample, depth, o, d, T, L, rays, stk_node, stk_min, stk_max);
+					if (last) alive = false;  // trace(0, ..) returns black: renderer.cpp:438-439
+					if (!alive) B.sample_rad[id] = make_float4(L.x, L.y, L.z, 1.0f);
+				}
+				// wave-level stream compaction: ballot + lane prefix count
+				const uint64_t mask = __ballot(alive);
+				if (alive) {
+					const uint32_t pos = n_out + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+					qout[pos] = make_float4(o.x, o.y, o.z, __uint_as_float(id));
+					qout[kChunk + pos] = make_float4(d.x, d.y, d.z, T.x);
+					qout[2 * kChunk + pos] = make_float4(T.y, T.z, L.x, L.y);
+					qout[3 * kChunk + pos] = make_float4(L.z, 0.f, 0.f, 0.f);
+				}
+				n_out += (uint32_t)__popcll(mask);
+			}
+			n_in = n_out;
+			// the wave re-reads (next depth) what OTHER lanes of this wave just wrote
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		}
+	}
+	// ray counter: one atomic per wave
+	for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+	if (lane == 0 && rays) atomicAdd(B.ray_counter, (unsigned long long)rays);
+}
+
+// Adds the pass's samples of each pixel, in sample order, into the accumulation buffer (sums).
+__global__ void k_resolve(const float4* __restrict__ sample_rad, float4* __restrict__ accum, uint32_t n_pixels, uint32_t pass_spp) {
+	uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n_pixels) return;
+	float4 a = accum[p];
+	for (uint32_t s = 0; s < pass_spp; s++) {
+		float4 r = sample_rad[(size_t)s * n_pixels + p];
+		a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+	}
+	accum[p] = a;
+}
+
+// ------------------------------------------------------------------------------------ batch intersect
+template <bool LDS>
+__global__ void __launch_bounds__(kBlock) k_intersect_batch(DevScene S, IntersectArgs A) {
+	const Geom g = stage_geometry<LDS>(S, g_smem);
+	uint32_t stk_node[kStack];
+	float stk_min[kStack], stk_max[kStack];
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (size_t)gridDim.x * blockDim.x) {
+		V3 o = mk(A.ox[i], A.oy[i], A.oz[i]), d = mk(A.dx[i], A.dy[i], A.dz[i]);
+		SceneHit h;
+		bool hit = scene_traverse(S, g, o, d, h, stk_node, stk_min, stk_max);
+		A.distance[i] = hit ? h.dist : -1.0f;
+		A.surface[i] = hit ? h.surface : -1;
+		A.triangle[i] = hit ? (int32_t)(h.tri - S.surfaces[h.surface].tri_base) : -1;
+		A.b0[i] = hit ? h.b0 : 0.f; A.b1[i] = hit ? h.b1 : 0.f; A.b2[i] = hit ? h.b2 : 0.f;
+		if (A.px || A.nx || A.u) {
+			Surf sf = {};
+			V3 sn = {0, 0, 0};
+			if (hit) { hit_attributes(S, g, h, sf); sn = shading_normal(sf); }
+			if (A.px) { A.px[i] = sf.pos.x; A.py[i] = sf.pos.y; A.pz[i] = sf.pos.z; }
+			if (A.nx) { A.nx[i] = sn.x; A.ny[i] = sn.y; A.nz[i] = sn.z; }
+			if (A.u) { A.u[i] = sf.u; A.v[i] = sf.v; }
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------ tonemap + encode
+// core::tonemap_approx_aces (core/utils.hpp:29-36) + image::image::write (image/image.cpp:143-154)
+DEV float aces1(float x) {
+	float v = (x * (2.51F * x + 0.03F)) / (x * (2.43F * x + 0.59F) + 0.14F);
+	v = 0 > v ? 0 : v;
+	v = 1 < v ? 1 : v;
+	return v;
+}
+DEV uint32_t quant8(float v) { return (uint32_t)(uint8_t)(int)(v * 255 + 0.5F); }
+__global__ void k_tonemap(const float4* __restrict__ accum, uint32_t n_pixels, float spp, uchar4* __restrict__ out) {
+	uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n_pixels) return;
+	float4 a = accum[p];
+	float r = aces1(a.x / spp), g = aces1(a.y / spp), b = aces1(a.z / spp);
+	// math::pow(value, 1 / 2.2F) is powf; evaluated here in double and rounded once so that the result is
+	// the correctly rounded float in all but ~1e-8 of cases (glibc's powf is within 1 ulp of it)
+	const double ig = (double)(1 / 2.2F);
+	uchar4 o;
+	o.x = (unsigned char)quant8((float)pow((double)r, ig));
+	o.y = (unsigned char)quant8((float)pow((double)g, ig));
+	o.z = (unsigned char)quant8((float)pow((double)b, ig));
+	o.w = (unsigned char)quant8(a.w / spp);
+	out[p] = o;
+}
+
+// ------------------------------------------------------------------------------------ launchers
+static hipError_t set_lds(const void* fn, size_t bytes) {
+	return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, bool lds, size_t lds_bytes, int grid,
+                              hipStream_t stream) {
+	if (lds) {
+		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<true>), lds_bytes);
+		if (e != hipSuccess) return e;
+		hipLaunchKernelGGL(k_render_pass<true>, dim3(grid), dim3(kBlock), lds_bytes, stream, S, P, B);
+	} else {
+		hipLaunchKernelGGL(k_render_pass<false>, dim3(grid), dim3(kBlock), 0, stream, S, P, B);
+	}
+	return hipGetLastError();
+}
+hipError_t launch_resolve(const float4* sample_rad, float4* accum, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream) {
+	hipLaunchKernelGGL(k_resolve, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, sample_rad, accum, n_pixels, pass_spp);
+	return hipGetLastError();
+}
+hipError_t launch_intersect(const DevScene& S, const IntersectArgs& A, bool lds, size_t lds_bytes, int grid, hipStream_t stream) {
+	if (lds) {
+		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_intersect_batch<true>), lds_bytes);
+		if (e != hipSuccess) return e;
+		hipLaunchKernelGGL(k_intersect_batch<true>, dim3(grid), dim3(kBlock), lds_bytes, stream, S, A);
+	} else {
+		hipLaunchKernelGGL(k_intersect_batch<false>, dim3(grid), dim3(kBlock), 0, stream, S, A);
+	}
+	return hipGetLastError();
+}
+hipError_t launch_tonemap(const float4* accum, uint32_t n_pixels, float spp, uchar4* out, hipStream_t stream) {
+	hipLaunchKernelGGL(k_tonemap, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, accum, n_pixels, spp, out);
+	return hipGetLastError();
+}
+
+}  // namespace ptx

@@ -1,0 +1,61 @@
+// Kernel argument blocks and launchers shared by kernels.hip and ptx_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "flat_scene.hpp"
+
+namespace ptx {
+
+constexpr int kBlock = 1024;      // threads per workgroup: 16 waves = 4 per SIMD, one workgroup per CU
+constexpr uint32_t kChunk = 1024; // camera paths a wave takes per counter fetch (16 wave-iterations)
+
+// Device view of a FlatScene (all pointers are device pointers).
+struct DevScene {
+	const ModelRec* models;
+	const SurfaceRec* surfaces;
+	const MaterialRec* materials;
+	const uint2* nodes;
+	const uint32_t* refs;
+	const float4* tris;   // 3 per triangle
+	const float4* vattr;  // 2 per vertex
+	int32_t n_models;
+	uint32_t n_nodes, n_refs, n_tris;
+	CameraRec cam;
+	SunRec sun;
+};
+
+struct RenderParams {
+	uint32_t W, H;              // full image
+	uint32_t x0, y0, w, h;      // tile
+	uint32_t n_pixels;          // w*h
+	uint32_t sample0;           // first sample index of this pass
+	uint32_t pass_spp;          // samples per pixel in this pass
+	uint32_t bounces;
+	uint64_t n_paths;           // n_pixels * pass_spp
+	uint32_t seed_lo, seed_hi;
+	float env[3];
+};
+
+struct PassBuffers {
+	float4* queues;                   // [n_wave_slots][2][4][kChunk]
+	float4* sample_rad;               // [pass_spp][n_pixels]
+	uint32_t* chunk_counter;          // zeroed before each pass
+	unsigned long long* ray_counter;  // accumulates
+};
+
+struct IntersectArgs {
+	const float *ox, *oy, *oz, *dx, *dy, *dz;
+	size_t n;
+	float* distance; int32_t* surface; int32_t* triangle;
+	float *b0, *b1, *b2;
+	float *px, *py, *pz, *nx, *ny, *nz, *u, *v;  // optional groups (nullptr = skip)
+};
+
+hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, bool lds, size_t lds_bytes, int grid,
+                              hipStream_t stream);
+hipError_t launch_resolve(const float4* sample_rad, float4* accum, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream);
+hipError_t launch_intersect(const DevScene& S, const IntersectArgs& A, bool lds, size_t lds_bytes, int grid, hipStream_t stream);
+hipError_t launch_tonemap(const float4* accum, uint32_t n_pixels, float spp, uchar4* out, hipStream_t stream);
+
+}  // namespace ptx

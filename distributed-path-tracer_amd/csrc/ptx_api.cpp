@@ -1,0 +1,500 @@
+// C ABI of libptx_hip.so (declared in include/ptx.h). Host glue only: contexts, scene upload,
+// pass scheduling, staging of host buffers. All arithmetic of the hot path lives in kernels.hip;
+// there is no CPU fallback — GPU entry points fail with PTX_ERR_NO_DEVICE when no HIP device exists.
+#include <hip/hip_runtime.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ptx.h"
+#include "kernels.hpp"
+
+using namespace ptx;
+
+namespace {
+
+thread_local std::string g_err;
+int set_err(int code, const std::string& m) { g_err = m; return code; }
+#define HIP_TRY(expr)                                                                                           \
+	do {                                                                                                        \
+		hipError_t e_ = (expr);                                                                                 \
+		if (e_ != hipSuccess) return set_err(PTX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+	} while (0)
+
+bool is_device_ptr(const void* p) {
+	hipPointerAttribute_t a;
+	hipError_t e = hipPointerGetAttributes(&a, p);
+	if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+	return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+struct DevBuf {
+	void* p = nullptr;
+	size_t cap = 0;
+	hipError_t ensure(size_t bytes) {
+		if (bytes <= cap) return hipSuccess;
+		if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+		hipError_t e = hipMalloc(&p, bytes);
+		if (e == hipSuccess) cap = bytes;
+		return e;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+constexpr size_t kLdsBudget = 160 * 1024;  // per-CU LDS on gfx950; one workgroup may take all of it
+
+}  // namespace
+
+struct ptx_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	int n_cu = 0;
+	std::mutex mu;
+	DevBuf queues, sample_rad, counters, stage_a, stage_b;
+	std::vector<hipEvent_t> events;
+};
+
+struct ptx_scene {
+	ptx_ctx* ctx = nullptr;
+	FlatScene host;
+	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr;
+	DevScene dev{};
+	bool lds = false;
+	size_t lds_bytes = 0;
+};
+
+namespace {
+
+size_t pad16(size_t b) { return (b + 15) & ~(size_t)15; }
+
+int upload_scene(ptx_scene* sc) {
+	ptx_ctx* c = sc->ctx;
+	HIP_TRY(hipSetDevice(c->device));
+	FlatScene& h = sc->host;
+	auto up = [&](DevBuf& b, const void* src, size_t bytes, size_t padded) -> hipError_t {
+		hipError_t e = b.ensure(std::max<size_t>(padded, 16));
+		if (e != hipSuccess) return e;
+		e = hipMemsetAsync(b.p, 0, std::max<size_t>(padded, 16), c->stream);
+		if (e != hipSuccess) return e;
+		return bytes ? hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+	};
+	HIP_TRY(up(sc->d_models, h.models.data(), h.models.size() * sizeof(ModelRec), h.models.size() * sizeof(ModelRec)));
+	HIP_TRY(up(sc->d_surfaces, h.surfaces.data(), h.surfaces.size() * sizeof(SurfaceRec), h.surfaces.size() * sizeof(SurfaceRec)));
+	HIP_TRY(up(sc->d_materials, h.materials.data(), h.materials.size() * sizeof(MaterialRec), h.materials.size() * sizeof(MaterialRec)));
+	HIP_TRY(up(sc->d_nodes, h.kd_nodes.data(), h.kd_nodes.size() * 8, pad16(h.kd_nodes.size() * 8)));
+	HIP_TRY(up(sc->d_refs, h.kd_refs.data(), h.kd_refs.size() * 4, pad16(h.kd_refs.size() * 4)));
+	HIP_TRY(up(sc->d_tris, h.tris.data(), h.tris.size() * 48, h.tris.size() * 48));
+	HIP_TRY(up(sc->d_vattr, h.vattr.data(), h.vattr.size() * 32, h.vattr.size() * 32));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	DevScene& d = sc->dev;
+	d.models = (const ModelRec*)sc->d_models.p;
+	d.surfaces = (const SurfaceRec*)sc->d_surfaces.p;
+	d.materials = (const MaterialRec*)sc->d_materials.p;
+	d.nodes = (const uint2*)sc->d_nodes.p;
+	d.refs = (const uint32_t*)sc->d_refs.p;
+	d.tris = (const float4*)sc->d_tris.p;
+	d.vattr = (const float4*)sc->d_vattr.p;
+	d.n_models = (int32_t)h.models.size();
+	d.n_nodes = (uint32_t)h.kd_nodes.size();
+	d.n_refs = (uint32_t)h.kd_refs.size();
+	d.n_tris = (uint32_t)h.tris.size();
+	d.cam = h.camera;
+	d.sun = h.sun;
+	sc->lds_bytes = h.tris.size() * 48 + pad16(h.kd_nodes.size() * 8) + pad16(h.kd_refs.size() * 4);
+	sc->lds = sc->lds_bytes <= kLdsBudget;
+	return PTX_OK;
+}
+
+int finish_scene(ptx_ctx* ctx, ptx_scene* sc, ptx_scene** out) {
+	sc->ctx = ctx;
+	if (ctx) {
+		std::lock_guard<std::mutex> lk(ctx->mu);
+		int rc = upload_scene(sc);
+		if (rc != PTX_OK) { delete sc; return rc; }
+	} else {
+		sc->lds_bytes = sc->host.tris.size() * 48 + pad16(sc->host.kd_nodes.size() * 8) + pad16(sc->host.kd_refs.size() * 4);
+		sc->lds = sc->lds_bytes <= kLdsBudget;
+	}
+	*out = sc;
+	return PTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ptx_last_error(void) { return g_err.c_str(); }
+const char* ptx_version(void) { return "ptx_hip 0.1 (gfx950)"; }
+
+int ptx_ctx_create(int device, ptx_ctx** out) {
+	if (!out) return set_err(PTX_ERR_INVALID, "ptx_ctx_create: out is NULL");
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) {
+		(void)hipGetLastError();
+		return set_err(PTX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+	}
+	if (device < 0 || device >= n) return set_err(PTX_ERR_INVALID, "device ordinal out of range");
+	HIP_TRY(hipSetDevice(device));
+	ptx_ctx* c = new ptx_ctx;
+	c->device = device;
+	hipDeviceProp_t prop;
+	e = hipGetDeviceProperties(&prop, device);
+	if (e != hipSuccess) { delete c; return set_err(PTX_ERR_HIP, hipGetErrorString(e)); }
+	c->n_cu = prop.multiProcessorCount;
+	e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+	if (e != hipSuccess) { delete c; return set_err(PTX_ERR_HIP, hipGetErrorString(e)); }
+	*out = c;
+	return PTX_OK;
+}
+
+void ptx_ctx_destroy(ptx_ctx* c) {
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
+	c->queues.release(); c->sample_rad.release(); c->counters.release(); c->stage_a.release(); c->stage_b.release();
+	(void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+void* ptx_ctx_stream(ptx_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int ptx_ctx_synchronize(ptx_ctx* c) {
+	if (!c) return set_err(PTX_ERR_INVALID, "ctx is NULL");
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return PTX_OK;
+}
+
+int ptx_scene_load_gltf(ptx_ctx* ctx, const char* path, const ptx_load_opts* opts, ptx_scene** out) {
+	if (!path || !out) return set_err(PTX_ERR_INVALID, "ptx_scene_load_gltf: NULL argument");
+	ptx_scene* sc = new ptx_scene;
+	try {
+		load_gltf(path, opts ? opts->camera_index : 0u, opts ? opts->sun_light_index : 0u, sc->host);
+	} catch (const Error& e) {
+		delete sc;
+		return set_err(e.code, e.msg);
+	} catch (const std::exception& e) {
+		delete sc;
+		return set_err(PTX_ERR_PARSE, e.what());
+	}
+	return finish_scene(ctx, sc, out);
+}
+
+int ptx_scene_from_arrays(ptx_ctx* ctx, const ptx_scene_desc* d, ptx_scene** out) {
+	if (!d || !out) return set_err(PTX_ERR_INVALID, "ptx_scene_from_arrays: NULL argument");
+	if (!d->camera || (d->n_models && (!d->model_xform || !d->model_surf)) ||
+	    (d->n_surfaces && (!d->surf_range || !d->vertices || !d->triangles || !d->materials)))
+		return set_err(PTX_ERR_INVALID, "ptx_scene_from_arrays: missing array");
+	ptx_scene* sc = new ptx_scene;
+	FlatScene& h = sc->host;
+	try {
+		h.model_xform.assign(d->model_xform, d->model_xform + 12 * (size_t)d->n_models);
+		h.model_surf.assign(d->model_surf, d->model_surf + 2 * (size_t)d->n_models);
+		size_t nv = 0, nt = 0;
+		for (uint32_t s = 0; s < d->n_surfaces; s++) {
+			const int32_t* r = d->surf_range + 4 * (size_t)s;
+			if (r[0] < 0 || r[1] < 0 || r[2] < 0 || r[3] < 0) throw Error{PTX_ERR_INVALID, "negative surface range"};
+			int32_t rg[8] = {r[0], r[1], r[2], r[3], 0, 0, 0, 0};
+			h.surf_range.insert(h.surf_range.end(), rg, rg + 8);
+			nv = std::max(nv, (size_t)r[0] + r[1]);
+			nt = std::max(nt, (size_t)r[2] + r[3]);
+		}
+		h.vertices.assign(d->vertices, d->vertices + 11 * nv);
+		h.triangles.assign(d->triangles, d->triangles + 3 * nt);
+		for (uint32_t s = 0; s < d->n_surfaces; s++) {
+			const int32_t* r = &h.surf_range[8 * (size_t)s];
+			for (int32_t t = 0; t < 3 * r[3]; t++)
+				if (h.triangles[3 * (size_t)r[2] + t] >= (uint32_t)r[1]) throw Error{PTX_ERR_INVALID, "vertex index out of range"};
+		}
+		for (uint32_t m = 0; m < d->n_models; m++) {
+			int32_t f = h.model_surf[2 * m], n = h.model_surf[2 * m + 1];
+			if (f < 0 || n < 0 || (uint32_t)(f + n) > d->n_surfaces) throw Error{PTX_ERR_INVALID, "model surface range out of bounds"};
+			h.model_names.push_back("model" + std::to_string(m));
+		}
+		h.materials_raw.assign(d->materials, d->materials + 11 * (size_t)d->n_surfaces);
+		h.material_tex.assign(7 * (size_t)d->n_surfaces, 0);
+		finalize_scene(h, d->camera, d->sun);
+	} catch (const Error& e) {
+		delete sc;
+		return set_err(e.code, e.msg);
+	} catch (const std::exception& e) {
+		delete sc;
+		return set_err(PTX_ERR_INVALID, e.what());
+	}
+	return finish_scene(ctx, sc, out);
+}
+
+void ptx_scene_destroy(ptx_scene* sc) {
+	if (!sc) return;
+	if (sc->ctx) {
+		std::lock_guard<std::mutex> lk(sc->ctx->mu);
+		(void)hipSetDevice(sc->ctx->device);
+		(void)hipStreamSynchronize(sc->ctx->stream);
+		sc->d_models.release(); sc->d_surfaces.release(); sc->d_materials.release(); sc->d_nodes.release();
+		sc->d_refs.release(); sc->d_tris.release(); sc->d_vattr.release();
+	}
+	delete sc;
+}
+
+int ptx_scene_get_info(const ptx_scene* sc, ptx_scene_info* info) {
+	if (!sc || !info) return set_err(PTX_ERR_INVALID, "NULL argument");
+	const FlatScene& h = sc->host;
+	info->n_models = (uint32_t)h.models.size();
+	info->n_surfaces = (uint32_t)h.surfaces.size();
+	info->n_vertices = (uint32_t)(h.vertices.size() / 11);
+	info->n_triangles = (uint32_t)h.tris.size();
+	info->n_kd_nodes = (uint32_t)h.kd_nodes.size();
+	info->n_kd_refs = (uint32_t)h.kd_refs.size();
+	info->kd_max_depth = h.kd_max_depth;
+	info->has_sun = h.sun.present;
+	info->geometry_bytes = (uint32_t)sc->lds_bytes;
+	info->lds_resident = sc->lds ? 1u : 0u;
+	return PTX_OK;
+}
+
+int64_t ptx_scene_get_array(const ptx_scene* sc, ptx_array which, void* dst, size_t dst_bytes) {
+	if (!sc) { set_err(PTX_ERR_INVALID, "scene is NULL"); return -1; }
+	const FlatScene& h = sc->host;
+	const void* src = nullptr;
+	size_t bytes = 0, elem = 4;
+	std::vector<float> tmp;
+	std::string names;
+	switch (which) {
+	case PTX_ARR_MODEL_XFORM: src = h.model_xform.data(); bytes = h.model_xform.size() * 4; break;
+	case PTX_ARR_MODEL_AABB:
+		for (auto& m : h.models) { tmp.insert(tmp.end(), m.bmin, m.bmin + 3); tmp.insert(tmp.end(), m.bmax, m.bmax + 3); }
+		src = tmp.data(); bytes = tmp.size() * 4; break;
+	case PTX_ARR_MODEL_SURF: src = h.model_surf.data(); bytes = h.model_surf.size() * 4; break;
+	case PTX_ARR_SURF_RANGE: src = h.surf_range.data(); bytes = h.surf_range.size() * 4; break;
+	case PTX_ARR_MESH_AABB:
+		for (auto& s : h.surfaces) { tmp.insert(tmp.end(), s.bmin, s.bmin + 3); tmp.insert(tmp.end(), s.bmax, s.bmax + 3); }
+		src = tmp.data(); bytes = tmp.size() * 4; break;
+	case PTX_ARR_VERTICES: src = h.vertices.data(); bytes = h.vertices.size() * 4; break;
+	case PTX_ARR_TRIANGLES: src = h.triangles.data(); bytes = h.triangles.size() * 4; break;
+	case PTX_ARR_MATERIALS: src = h.materials_raw.data(); bytes = h.materials_raw.size() * 4; break;
+	case PTX_ARR_KD_NODES: src = h.kd_nodes.data(); bytes = h.kd_nodes.size() * 8; break;
+	case PTX_ARR_KD_REFS: src = h.kd_refs.data(); bytes = h.kd_refs.size() * 4; break;
+	case PTX_ARR_CAMERA:
+		tmp.assign(h.camera.origin, h.camera.origin + 3); tmp.insert(tmp.end(), h.camera.basis, h.camera.basis + 9);
+		tmp.push_back(h.camera.fov); tmp.push_back(h.camera.tan_half_fov);
+		src = tmp.data(); bytes = tmp.size() * 4; break;
+	case PTX_ARR_SUN:
+		if (h.sun.present) { tmp.assign(h.sun.basis, h.sun.basis + 9); tmp.insert(tmp.end(), h.sun.energy, h.sun.energy + 3); tmp.push_back(h.sun.angular_radius); }
+		src = tmp.data(); bytes = tmp.size() * 4; break;
+	case PTX_ARR_MODEL_NAMES:
+		for (auto& n : h.model_names) names += n + "\n";
+		src = names.data(); bytes = names.size(); elem = 1; break;
+	default: set_err(PTX_ERR_INVALID, "unknown array id"); return -1;
+	}
+	if (dst) {
+		if (dst_bytes < bytes) { set_err(PTX_ERR_INVALID, "destination too small"); return -1; }
+		if (bytes) memcpy(dst, src, bytes);
+	}
+	return (int64_t)(bytes / elem);
+}
+
+int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_render_stats* stats) {
+	if (!sc || !cfg || !accum) return set_err(PTX_ERR_INVALID, "ptx_render: NULL argument");
+	if (!sc->ctx) return set_err(PTX_ERR_NO_DEVICE, "ptx_render: scene was created without a GPU context (no CPU path exists)");
+	if (sc->host.any_texture) return set_err(PTX_ERR_UNSUPPORTED, "ptx_render: textured materials are not built yet");
+	if (!cfg->W || !cfg->H || !cfg->bounces) return set_err(PTX_ERR_INVALID, "ptx_render: W, H and bounces must be > 0");
+	uint32_t x0 = cfg->x0, y0 = cfg->y0, w = cfg->w, h = cfg->h;
+	if (w == 0 && h == 0) { x0 = 0; y0 = 0; w = cfg->W; h = cfg->H; }
+	if (!w || !h || (uint64_t)x0 + w > cfg->W || (uint64_t)y0 + h > cfg->H) return set_err(PTX_ERR_INVALID, "ptx_render: tile outside the image");
+	if (cfg->bounces > 0xFFFFu) return set_err(PTX_ERR_INVALID, "ptx_render: bounces > 65535");
+	ptx_ctx* c = sc->ctx;
+	std::lock_guard<std::mutex> lk(c->mu);
+	HIP_TRY(hipSetDevice(c->device));
+	const uint64_t n_pixels = (uint64_t)w * h;
+	if (n_pixels > 0x7FFFFFFFull) return set_err(PTX_ERR_INVALID, "ptx_render: tile too large");
+	if (stats) *stats = ptx_render_stats{};
+	if (cfg->spp == 0) return PTX_OK;
+
+	// samples of every pixel per launch: enough paths to fill the chip many times over, bounded workspace
+	uint32_t pass_spp = cfg->spp_per_pass;
+	if (pass_spp == 0) {
+		const uint64_t target_paths = 16ull << 20;
+		pass_spp = (uint32_t)std::max<uint64_t>(1, target_paths / n_pixels);
+	}
+	pass_spp = std::min(pass_spp, cfg->spp);
+	while ((uint64_t)pass_spp * n_pixels > 0xFFFFFFFFull) pass_spp--;  // path ids are 32-bit
+	if (pass_spp == 0) return set_err(PTX_ERR_INVALID, "ptx_render: tile too large for one pass");
+
+	const int grid = c->n_cu;
+	const size_t n_slots = (size_t)grid * (kBlock / 64);
+	HIP_TRY(c->queues.ensure(n_slots * 2 * 4 * kChunk * sizeof(float4)));
+	HIP_TRY(c->sample_rad.ensure((size_t)pass_spp * n_pixels * sizeof(float4)));
+	HIP_TRY(c->counters.ensure(64));
+	uint32_t* chunk_counter = (uint32_t*)c->counters.p;
+	unsigned long long* ray_counter = (unsigned long long*)((char*)c->counters.p + 16);
+	HIP_TRY(hipMemsetAsync(c->counters.p, 0, 64, c->stream));
+
+	const bool dev_accum = is_device_ptr(accum);
+	float4* d_accum = (float4*)accum;
+	if (!dev_accum) {
+		HIP_TRY(c->stage_a.ensure(n_pixels * sizeof(float4)));
+		d_accum = (float4*)c->stage_a.p;
+		HIP_TRY(hipMemcpyAsync(d_accum, accum, n_pixels * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+	}
+
+	const uint32_t n_pass = (cfg->spp + pass_spp - 1) / pass_spp;
+	if (stats)
+		while (c->events.size() < 2 * (size_t)n_pass) {
+			hipEvent_t ev;
+			HIP_TRY(hipEventCreate(&ev));
+			c->events.push_back(ev);
+		}
+	PassBuffers B{(float4*)c->queues.p, (float4*)c->sample_rad.p, chunk_counter, ray_counter};
+	for (uint32_t p = 0; p < n_pass; p++) {
+		RenderParams P{};
+		P.W = cfg->W; P.H = cfg->H; P.x0 = x0; P.y0 = y0; P.w = w; P.h = h;
+		P.n_pixels = (uint32_t)n_pixels;
+		P.sample0 = cfg->sample0 + p * pass_spp;
+		P.pass_spp = std::min(pass_spp, cfg->spp - p * pass_spp);
+		P.bounces = cfg->bounces;
+		P.n_paths = (uint64_t)P.pass_spp * n_pixels;
+		P.seed_lo = cfg->seed_lo; P.seed_hi = cfg->seed_hi;
+		memcpy(P.env, cfg->env, sizeof P.env);
+		HIP_TRY(hipMemsetAsync(chunk_counter, 0, 4, c->stream));
+		if (stats) HIP_TRY(hipEventRecord(c->events[2 * p], c->stream));
+		HIP_TRY(launch_render_pass(sc->dev, P, B, sc->lds, sc->lds_bytes, grid, c->stream));
+		if (stats) HIP_TRY(hipEventRecord(c->events[2 * p + 1], c->stream));
+		HIP_TRY(launch_resolve(B.sample_rad, d_accum, P.n_pixels, P.pass_spp, c->stream));
+	}
+	if (!dev_accum) HIP_TRY(hipMemcpyAsync(accum, d_accum, n_pixels * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+	if (stats || !dev_accum) HIP_TRY(hipStreamSynchronize(c->stream));
+	if (stats) {
+		unsigned long long rays = 0;
+		HIP_TRY(hipMemcpy(&rays, ray_counter, 8, hipMemcpyDeviceToHost));
+		stats->rays = rays;
+		stats->samples = (uint64_t)cfg->spp * n_pixels;
+		stats->passes = n_pass;
+		double ms = 0;
+		for (uint32_t p = 0; p < n_pass; p++) {
+			float t = 0;
+			HIP_TRY(hipEventElapsedTime(&t, c->events[2 * p], c->events[2 * p + 1]));
+			ms += t;
+		}
+		stats->kernel_ms = ms;
+	}
+	return PTX_OK;
+}
+
+int ptx_intersect_batch(ptx_scene* sc, const ptx_rays* r, size_t n, const ptx_hits* hh) {
+	if (!sc || !r || !hh) return set_err(PTX_ERR_INVALID, "ptx_intersect_batch: NULL argument");
+	if (!sc->ctx) return set_err(PTX_ERR_NO_DEVICE, "ptx_intersect_batch: scene was created without a GPU context (no CPU path exists)");
+	if (n == 0) return PTX_OK;
+	if (!r->ox || !r->oy || !r->oz || !r->dx || !r->dy || !r->dz || !hh->distance || !hh->surface || !hh->triangle || !hh->b0 || !hh->b1 || !hh->b2)
+		return set_err(PTX_ERR_INVALID, "ptx_intersect_batch: required array is NULL");
+	auto group_ok = [](const void* a, const void* b, const void* c) { return (!a && !b && !c) || (a && b && c); };
+	if (!group_ok(hh->px, hh->py, hh->pz) || !group_ok(hh->nx, hh->ny, hh->nz) || ((hh->u != nullptr) != (hh->v != nullptr)))
+		return set_err(PTX_ERR_INVALID, "ptx_intersect_batch: optional outputs must be given as whole groups");
+	ptx_ctx* c = sc->ctx;
+	std::lock_guard<std::mutex> lk(c->mu);
+	HIP_TRY(hipSetDevice(c->device));
+	const bool dev = is_device_ptr(r->ox);
+	IntersectArgs A{};
+	A.n = n;
+	const int n_out = 6 + (hh->px ? 3 : 0) + (hh->nx ? 3 : 0) + (hh->u ? 2 : 0);
+	if (dev) {
+		A.ox = r->ox; A.oy = r->oy; A.oz = r->oz; A.dx = r->dx; A.dy = r->dy; A.dz = r->dz;
+		A.distance = hh->distance; A.surface = hh->surface; A.triangle = hh->triangle;
+		A.b0 = hh->b0; A.b1 = hh->b1; A.b2 = hh->b2;
+		A.px = hh->px; A.py = hh->py; A.pz = hh->pz; A.nx = hh->nx; A.ny = hh->ny; A.nz = hh->nz; A.u = hh->u; A.v = hh->v;
+	} else {
+		HIP_TRY(c->stage_a.ensure(6 * n * 4));
+		HIP_TRY(c->stage_b.ensure((size_t)n_out * n * 4));
+		float* in = (float*)c->stage_a.p;
+		const float* src[6] = {r->ox, r->oy, r->oz, r->dx, r->dy, r->dz};
+		for (int k = 0; k < 6; k++) HIP_TRY(hipMemcpyAsync(in + k * n, src[k], n * 4, hipMemcpyHostToDevice, c->stream));
+		A.ox = in; A.oy = in + n; A.oz = in + 2 * n; A.dx = in + 3 * n; A.dy = in + 4 * n; A.dz = in + 5 * n;
+		float* o = (float*)c->stage_b.p;
+		A.distance = o; A.surface = (int32_t*)(o + n); A.triangle = (int32_t*)(o + 2 * n);
+		A.b0 = o + 3 * n; A.b1 = o + 4 * n; A.b2 = o + 5 * n;
+		size_t k = 6;
+		if (hh->px) { A.px = o + k * n; A.py = o + (k + 1) * n; A.pz = o + (k + 2) * n; k += 3; }
+		if (hh->nx) { A.nx = o + k * n; A.ny = o + (k + 1) * n; A.nz = o + (k + 2) * n; k += 3; }
+		if (hh->u) { A.u = o + k * n; A.v = o + (k + 1) * n; }
+	}
+	const int grid = (int)std::min<size_t>((size_t)c->n_cu, (n + kBlock - 1) / kBlock);
+	HIP_TRY(launch_intersect(sc->dev, A, sc->lds, sc->lds_bytes, grid, c->stream));
+	if (!dev) {
+		void* dst[14] = {hh->distance, hh->surface, hh->triangle, hh->b0, hh->b1, hh->b2, hh->px, hh->py, hh->pz, hh->nx, hh->ny, hh->nz, hh->u, hh->v};
+		const void* srcs[14] = {A.distance, A.surface, A.triangle, A.b0, A.b1, A.b2, A.px, A.py, A.pz, A.nx, A.ny, A.nz, A.u, A.v};
+		for (int k = 0; k < 14; k++)
+			if (dst[k]) HIP_TRY(hipMemcpyAsync(dst[k], srcs[k], n * 4, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	return PTX_OK;
+}
+
+int ptx_tonemap_encode(ptx_ctx* c, const float* accum, uint32_t W, uint32_t H, uint32_t spp, uint8_t* rgba8) {
+	if (!c) return set_err(PTX_ERR_NO_DEVICE, "ptx_tonemap_encode: no GPU context (no CPU path exists)");
+	if (!accum || !rgba8 || !W || !H || !spp) return set_err(PTX_ERR_INVALID, "ptx_tonemap_encode: bad argument");
+	std::lock_guard<std::mutex> lk(c->mu);
+	HIP_TRY(hipSetDevice(c->device));
+	const size_t n = (size_t)W * H;
+	const bool dev_in = is_device_ptr(accum), dev_out = is_device_ptr(rgba8);
+	const float4* d_in = (const float4*)accum;
+	uchar4* d_out = (uchar4*)rgba8;
+	if (!dev_in) {
+		HIP_TRY(c->stage_a.ensure(n * 16));
+		HIP_TRY(hipMemcpyAsync(c->stage_a.p, accum, n * 16, hipMemcpyHostToDevice, c->stream));
+		d_in = (const float4*)c->stage_a.p;
+	}
+	if (!dev_out) {
+		HIP_TRY(c->stage_b.ensure(n * 4));
+		d_out = (uchar4*)c->stage_b.p;
+	}
+	HIP_TRY(launch_tonemap(d_in, (uint32_t)n, (float)spp, d_out, c->stream));
+	if (!dev_out) {
+		HIP_TRY(hipMemcpyAsync(rgba8, d_out, n * 4, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	return PTX_OK;
+}
+
+int ptx_encode_png(const uint8_t* rgba8, uint32_t W, uint32_t H, uint8_t** png, size_t* png_bytes) {
+	if (!rgba8 || !png || !png_bytes || !W || !H) return set_err(PTX_ERR_INVALID, "ptx_encode_png: bad argument");
+	const size_t row = (size_t)W * 4;
+	std::vector<uint8_t> raw((row + 1) * H);
+	for (uint32_t y = 0; y < H; y++) {
+		raw[(row + 1) * y] = 0;  // filter type None
+		memcpy(&raw[(row + 1) * y + 1], rgba8 + row * y, row);
+	}
+	uLongf zcap = compressBound((uLong)raw.size());
+	std::vector<uint8_t> z(zcap);
+	if (compress2(z.data(), &zcap, raw.data(), (uLong)raw.size(), 6) != Z_OK) return set_err(PTX_ERR_INVALID, "zlib compress2 failed");
+	const size_t total = 8 + (12 + 13) + (12 + zcap) + 12;
+	uint8_t* out = (uint8_t*)malloc(total);
+	if (!out) return set_err(PTX_ERR_INVALID, "out of memory");
+	uint8_t* p = out;
+	static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+	memcpy(p, sig, 8); p += 8;
+	auto be32 = [](uint8_t* q, uint32_t v) { q[0] = v >> 24; q[1] = v >> 16; q[2] = v >> 8; q[3] = v; };
+	auto chunk = [&](const char* type, const uint8_t* data, uint32_t len) {
+		be32(p, len); memcpy(p + 4, type, 4);
+		if (len) memcpy(p + 8, data, len);
+		be32(p + 8 + len, (uint32_t)crc32(0, p + 4, len + 4));
+		p += 12 + len;
+	};
+	uint8_t ihdr[13];
+	be32(ihdr, W); be32(ihdr + 4, H);
+	ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;  // 8-bit RGBA
+	chunk("IHDR", ihdr, 13);
+	chunk("IDAT", z.data(), (uint32_t)zcap);
+	chunk("IEND", nullptr, 0);
+	*png = out;
+	*png_bytes = total;
+	return PTX_OK;
+}
+
+void ptx_free(void* p) { free(p); }
+
+}  // extern "C"

@@ -1,0 +1,268 @@
+// Host-side scene finalisation: AABBs, SAH KD-trees with the reference's topology, flattening.
+//
+// What is reproduced (so that traversal order, tie-breaks and therefore pixels match the reference):
+//   mesh::recalculate_aabb      LIB/core/mesh.cpp:254-261   (+epsilon pad; aabb::clear quirk aabb.cpp:29-32)
+//   model::recalculate_aabb     LIB/scene/model.cpp:13-18
+//   kd_tree_builder::init_node_sah / split_triangles / split_aabb   LIB/core/mesh.cpp:21-80,131-247
+//   mesh::build_kd_tree         LIB/core/mesh.cpp:263-298   (SAH, max depth 25)
+//   transform::inverse          LIB/scene/transform.cpp:33-36, mat3 inverse LIB/math/mat3.inl:245-263
+// How it differs: the tree is built over index lists (no triangle copies), emitted breadth-first into
+// 8-byte nodes whose children are adjacent, and leaf references hold GLOBAL triangle ids.
+// All arithmetic is float32 in the reference's operation order; build with -ffp-contract=off.
+#include "flat_scene.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <limits>
+#include <tuple>
+
+namespace ptx {
+namespace {
+
+constexpr float kEps = 0.0001f;  // math::epsilon, LIB/math/math.hpp:16
+
+struct F3 { float v[3]; };
+struct Box { float lo[3], hi[3]; };
+
+inline float pick_max(float a, float b) { return b > a ? b : a; }  // math::max, math.inl:169
+inline float pick_min(float a, float b) { return b < a ? b : a; }  // math::min, math.inl:179
+
+inline void box_reset(Box& b) {
+	// aabb::clear(): min = FLT_MAX, max = FLT_MIN (the smallest POSITIVE float, not -FLT_MAX) — kept on purpose (Q2)
+	for (int k = 0; k < 3; k++) { b.lo[k] = std::numeric_limits<float>::max(); b.hi[k] = std::numeric_limits<float>::min(); }
+}
+inline void box_grow(Box& b, const float* p) {
+	for (int k = 0; k < 3; k++) { b.lo[k] = pick_min(b.lo[k], p[k]); b.hi[k] = pick_max(b.hi[k], p[k]); }
+}
+inline float box_area(const Box& b) {
+	float wx = b.hi[0] - b.lo[0], wy = b.hi[1] - b.lo[1], wz = b.hi[2] - b.lo[2];
+	return (wx * wy + wy * wz + wx * wz) * 2;
+}
+
+// ---- 3x3 helpers on column-major float[9] = {x.x,x.y,x.z, y.x,...} ----
+inline void mat_inverse(const float* m, float* out) {
+	const float xx = m[0], xy = m[1], xz = m[2], yx = m[3], yy = m[4], yz = m[5], zx = m[6], zy = m[7], zz = m[8];
+	float det1 = +(yy * zz - zy * yz);
+	float det2 = -(xy * zz - zy * xz);
+	float det3 = +(xy * yz - yy * xz);
+	float det = xx * det1 + yx * det2 + zx * det3;
+	float s = 1 / det;
+	float r[9] = {det1, det2, det3,
+	              -(yx * zz - zx * yz), +(xx * zz - zx * xz), -(xx * yz - yx * xz),
+	              +(yx * zy - zx * yy), -(xx * zy - zx * xy), +(xx * yy - yx * xy)};
+	for (int k = 0; k < 9; k++) out[k] = r[k] * s;
+}
+inline void mat_mul_vec(const float* m, const float* v, float* out) {  // rows dotted with v (mat3.inl:219-224)
+	for (int r = 0; r < 3; r++) out[r] = m[r] * v[0] + m[3 + r] * v[1] + m[6 + r] * v[2];
+}
+
+// ---- SAH builder -------------------------------------------------------------------------------
+struct BuildNode {
+	bool leaf = false;
+	uint8_t axis = 0;
+	float split = 0;
+	int32_t left = -1, right = -1;
+	std::vector<uint32_t> ids;  // leaf: mesh-local triangle ids, in ascending (= inherited) order
+};
+
+struct MeshBuilder {
+	const std::vector<F3>& pa; const std::vector<F3>& pb; const std::vector<F3>& pc;  // corner positions per triangle
+	std::vector<BuildNode> nodes;
+	uint32_t max_depth_seen = 0;
+
+	int32_t build(const Box& box, std::vector<uint32_t>&& ids, int levels_left, uint32_t depth) {
+		int32_t me = (int32_t)nodes.size();
+		nodes.emplace_back();
+		max_depth_seen = std::max(max_depth_seen, depth);
+		if (levels_left == 0) {
+			nodes[me].leaf = true;
+			nodes[me].ids = std::move(ids);
+			return me;
+		}
+		const size_t n = ids.size();
+		const float base_cost = n * box_area(box);
+		float best_cost = base_cost, best_split = 0;
+		int best_axis = 0;
+		// Same element type, comparator and std::sort as mesh.cpp:148-163 so that runs of equal keys
+		// come out in the same (implementation-defined) order as in the reference on this libstdc++.
+		std::vector<std::tuple<float, bool>> ev;
+		ev.reserve(n * 2);
+		for (int axis = 0; axis < 3; axis++) {
+			ev.clear();
+			for (uint32_t t : ids) {
+				float a = pa[t].v[axis], b = pb[t].v[axis], c = pc[t].v[axis];
+				ev.emplace_back(pick_min(pick_min(a, b), c), true);
+				ev.emplace_back(pick_max(pick_max(a, b), c), false);
+			}
+			std::sort(ev.begin(), ev.end(), [](auto& x, auto& y) { return std::get<0>(x) < std::get<0>(y); });
+			float split = 0;
+			uint32_t nl = 0, nr = (uint32_t)n;
+			for (size_t i = 0; i <= ev.size(); i++) {
+				if (i == 0) split = std::get<0>(ev.front()) - kEps;
+				else if (i == ev.size()) { nr--; split = std::get<0>(ev.back()) + kEps; }
+				else {
+					if (std::get<1>(ev[i - 1])) nl++;
+					else nr--;
+					if (std::get<0>(ev[i - 1]) == std::get<0>(ev[i])) continue;
+					split = (std::get<0>(ev[i - 1]) + std::get<0>(ev[i])) * 0.5F;
+				}
+				if (split <= box.lo[axis]) continue;
+				if (split >= box.hi[axis]) break;
+				Box l = box, r = box;
+				l.hi[axis] = split;
+				r.lo[axis] = split;
+				float cost = nl * box_area(l) + nr * box_area(r);
+				if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = split; }
+			}
+		}
+		if (!(best_cost < base_cost)) {
+			nodes[me].leaf = true;
+			nodes[me].ids = std::move(ids);
+			return me;
+		}
+		nodes[me].axis = (uint8_t)best_axis;
+		nodes[me].split = best_split;
+		Box l = box, r = box;
+		l.hi[best_axis] = best_split;
+		r.lo[best_axis] = best_split;
+		std::vector<uint32_t> lids, rids;
+		lids.reserve(n);
+		rids.reserve(n);
+		for (uint32_t t : ids) {  // a triangle goes left if ANY corner is < split, right if ANY corner is >= split
+			bool any_l = false, any_r = false;
+			const float c3[3] = {pa[t].v[best_axis], pb[t].v[best_axis], pc[t].v[best_axis]};
+			for (float c : c3) (c < best_split ? any_l : any_r) = true;
+			if (any_l) lids.push_back(t);
+			if (any_r) rids.push_back(t);
+		}
+		std::vector<uint32_t>().swap(ids);
+		if (!lids.empty()) { int32_t c = build(l, std::move(lids), levels_left - 1, depth + 1); nodes[me].left = c; }
+		if (!rids.empty()) { int32_t c = build(r, std::move(rids), levels_left - 1, depth + 1); nodes[me].right = c; }
+		return me;
+	}
+};
+
+}  // namespace
+
+void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
+	const size_t n_models = s.model_surf.size() / 2;
+	const size_t n_surf = s.surf_range.size() / 8;
+	s.models.assign(n_models, ModelRec{});
+	s.surfaces.assign(n_surf, SurfaceRec{});
+	s.materials.assign(n_surf, MaterialRec{});
+	s.kd_nodes.clear(); s.kd_refs.clear(); s.tris.clear(); s.vattr.clear();
+	s.kd_max_depth = 0;
+	s.any_texture = false;
+
+	// vertex attribute records (global vertex ids)
+	const size_t nv = s.vertices.size() / 11;
+	s.vattr.resize(nv);
+	for (size_t i = 0; i < nv; i++) {
+		const float* v = &s.vertices[11 * i];
+		s.vattr[i] = {v[5], v[6], v[7], v[3], v[8], v[9], v[10], v[4]};
+	}
+
+	for (size_t si = 0; si < n_surf; si++) {
+		int32_t* rg = &s.surf_range[8 * si];
+		const int32_t v0 = rg[0], nvs = rg[1], t0 = rg[2], nt = rg[3];
+		SurfaceRec& sr = s.surfaces[si];
+		Box mb;
+		box_reset(mb);
+		for (int32_t k = 0; k < nvs; k++) box_grow(mb, &s.vertices[11 * (size_t)(v0 + k)]);
+		for (int k = 0; k < 3; k++) { mb.lo[k] -= kEps; mb.hi[k] += kEps; }
+		memcpy(sr.bmin, mb.lo, 12);
+		memcpy(sr.bmax, mb.hi, 12);
+		sr.tri_base = (uint32_t)t0;
+
+		std::vector<F3> pa(nt), pb(nt), pc(nt);
+		for (int32_t t = 0; t < nt; t++) {
+			const uint32_t* ix = &s.triangles[3 * (size_t)(t0 + t)];
+			const float* a = &s.vertices[11 * (size_t)(v0 + ix[0])];
+			const float* b = &s.vertices[11 * (size_t)(v0 + ix[1])];
+			const float* c = &s.vertices[11 * (size_t)(v0 + ix[2])];
+			memcpy(pa[t].v, a, 12); memcpy(pb[t].v, b, 12); memcpy(pc[t].v, c, 12);
+			s.tris.push_back({a[0], a[1], a[2], (uint32_t)(v0 + ix[0]), b[0], b[1], b[2], (uint32_t)(v0 + ix[1]),
+			                  c[0], c[1], c[2], (uint32_t)(v0 + ix[2])});
+		}
+		MeshBuilder mbuild{pa, pb, pc, {}, 0};
+		std::vector<uint32_t> all(nt);
+		for (int32_t t = 0; t < nt; t++) all[t] = (uint32_t)t;
+		mbuild.build(mb, std::move(all), 25, 1);  // mesh.hpp:34: max_depth = 25
+		s.kd_max_depth = std::max(s.kd_max_depth, mbuild.max_depth_seen);
+
+		// breadth-first emission: children of a branch are adjacent; top levels come first
+		const uint32_t node0 = (uint32_t)s.kd_nodes.size(), ref0 = (uint32_t)s.kd_refs.size();
+		std::deque<std::pair<int32_t, uint32_t>> q;  // (build node, flat index)
+		s.kd_nodes.push_back({0, 0});
+		q.push_back({0, node0});
+		while (!q.empty()) {
+			auto [bi, fi] = q.front();
+			q.pop_front();
+			const BuildNode& bn = mbuild.nodes[bi];
+			if (bn.leaf) {
+				s.kd_nodes[fi] = kd_make_leaf((uint32_t)s.kd_refs.size(), (uint32_t)bn.ids.size());
+				for (uint32_t t : bn.ids) s.kd_refs.push_back((uint32_t)t0 + t);
+			} else {
+				bool hl = bn.left >= 0, hr = bn.right >= 0;
+				uint32_t first = (uint32_t)s.kd_nodes.size();
+				s.kd_nodes[fi] = kd_make_branch(bn.split, bn.axis, hl, hr, first);
+				if (hl) { s.kd_nodes.push_back({0, 0}); q.push_back({bn.left, first}); }
+				if (hr) { s.kd_nodes.push_back({0, 0}); q.push_back({bn.right, first + (hl ? 1u : 0u)}); }
+			}
+		}
+		sr.kd_root = node0;
+		rg[4] = (int32_t)node0; rg[5] = (int32_t)(s.kd_nodes.size() - node0);
+		rg[6] = (int32_t)ref0;  rg[7] = (int32_t)(s.kd_refs.size() - ref0);
+
+		const float* m = &s.materials_raw[11 * si];
+		MaterialRec& mr = s.materials[si];
+		mr.albedo[0] = m[0]; mr.albedo[1] = m[1]; mr.albedo[2] = m[2];
+		mr.opacity = m[3]; mr.roughness = m[4]; mr.metallic = m[5];
+		for (int k = 0; k < 3; k++) mr.emissive10[k] = m[6 + k] * 10;  // get_emissive(...) * 10, renderer.cpp:462
+		mr.ior = m[9];
+		mr.shadow_catcher = m[10] != 0 ? 1u : 0u;
+		mr.tex_mask = 0;
+		if (s.material_tex.size() >= 7 * (si + 1))
+			for (int k = 0; k < 7; k++) if (s.material_tex[7 * si + k]) mr.tex_mask |= 1u << k;
+		if (mr.tex_mask) s.any_texture = true;
+	}
+
+	for (size_t mi = 0; mi < n_models; mi++) {
+		ModelRec& mr = s.models[mi];
+		const float* x = &s.model_xform[12 * mi];
+		memcpy(mr.origin, x, 12);
+		memcpy(mr.basis, x + 3, 36);
+		mat_inverse(mr.basis, mr.inv_basis);
+		const float neg[3] = {-x[0], -x[1], -x[2]};
+		mat_mul_vec(mr.inv_basis, neg, mr.inv_origin);
+		// normal matrix = transpose(inverse(basis)): column k of the transpose is row k of the inverse
+		for (int c = 0; c < 3; c++)
+			for (int r = 0; r < 3; r++) mr.nmat[3 * c + r] = mr.inv_basis[3 * r + c];
+		mr.first_surface = s.model_surf[2 * mi];
+		mr.n_surfaces = s.model_surf[2 * mi + 1];
+		Box b;
+		box_reset(b);
+		for (int32_t k = 0; k < mr.n_surfaces; k++) {
+			box_grow(b, s.surfaces[mr.first_surface + k].bmin);
+			box_grow(b, s.surfaces[mr.first_surface + k].bmax);
+		}
+		memcpy(mr.bmin, b.lo, 12);
+		memcpy(mr.bmax, b.hi, 12);
+	}
+
+	memcpy(s.camera.origin, cam, 12);
+	memcpy(s.camera.basis, cam + 3, 36);
+	s.camera.fov = cam[12];
+	s.camera.tan_half_fov = std::tan(cam[12] * 0.5F);  // camera::set_fov, LIB/scene/camera.cpp:27-30
+	s.sun = SunRec{};
+	if (sun) {
+		memcpy(s.sun.basis, sun, 36);
+		memcpy(s.sun.energy, sun + 9, 12);
+		s.sun.angular_radius = sun[12];
+		s.sun.present = 1;
+	}
+}
+
+}  // namespace ptx

@@ -1,0 +1,175 @@
+/* ptx.h — C ABI of the MI355X-native path-tracing integrator (libptx_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of vmanam0451/distributed-path-tracer: the
+ * ray-intersection + Monte-Carlo shading integrator of path-tracer-core/path_tracer_lib.
+ * The reference has no FFI layer (the host links the library statically and calls C++ classes,
+ * path-tracer-core/CMakeLists.txt:44); each entry point below names the reference interface it
+ * replaces. Paths are relative to path-tracer-core/; LIB = path_tracer_lib/path_tracer.
+ *
+ * Conventions: plain pointers and sizes only; every function returns a ptx_status (0 = ok) and never
+ * throws; ptx_last_error() gives the thread-local message of the last failure. Buffers that the
+ * documentation marks "device or host" may be either: the library inspects the pointer
+ * (hipPointerGetAttributes) and stages host buffers through its own device workspace.
+ * A scene is immutable after creation; one context per GPU; calls on one context are serialised
+ * on that context's HIP stream.
+ */
+#ifndef PTX_H
+#define PTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ptx_status {
+	PTX_OK = 0,
+	PTX_ERR_INVALID = 1,    /* bad argument */
+	PTX_ERR_IO = 2,         /* file could not be read (LIB/core/renderer.cpp:64-69 only logs this and then crashes) */
+	PTX_ERR_PARSE = 3,      /* malformed glTF */
+	PTX_ERR_NO_CAMERA = 4,  /* "Scene does not contain camera #i." / "Scene is missing a camera." renderer.cpp:73-74,97-98 */
+	PTX_ERR_NO_DEVICE = 5,  /* no HIP device / host-only scene used for GPU work: the product never falls back to a CPU path */
+	PTX_ERR_HIP = 6,        /* HIP runtime error (message carries hipGetErrorString) */
+	PTX_ERR_UNSUPPORTED = 7 /* feature outside the built scope (e.g. textured materials), refused rather than rendered wrong */
+} ptx_status;
+
+typedef struct ptx_ctx ptx_ctx;     /* one per GPU: device, stream, workspace */
+typedef struct ptx_scene ptx_scene; /* flattened, immutable scene (+ its device copy) */
+
+const char* ptx_last_error(void);
+const char* ptx_version(void);
+
+/* ---- context ------------------------------------------------------------------------------------
+ * device >= 0: HIP device ordinal. Fails with PTX_ERR_NO_DEVICE when there is none. */
+int ptx_ctx_create(int device, ptx_ctx** out);
+void ptx_ctx_destroy(ptx_ctx* ctx);
+/* Stream the context launches on (hipStream_t as void*), for callers that time or order work. */
+void* ptx_ctx_stream(ptx_ctx* ctx);
+int ptx_ctx_synchronize(ptx_ctx* ctx);
+
+/* ---- scene load ---------------------------------------------------------------------------------
+ * Replaces core::renderer::load_gltf(path) (LIB/core/renderer.hpp:35, renderer.cpp:61-331) and the
+ * host's cloud::distributed_scene::load_scene (src/scene/scene.hpp:19): parses the glTF, builds the
+ * entity transforms, unpacks every primitive (with the reference's loader quirks), builds one SAH
+ * KD-tree per primitive with the reference's topology (LIB/core/mesh.cpp:131-298) and flattens all of
+ * it into pointer-free arrays. ctx may be NULL: the scene is then host-only (inspection, no GPU work). */
+typedef struct ptx_load_opts {
+	uint32_t camera_index;    /* renderer.hpp:31, default 0 */
+	uint32_t sun_light_index; /* renderer.hpp:32, default 0; 0xFFFFFFFF = renderer::no_sun_light */
+} ptx_load_opts;
+int ptx_scene_load_gltf(ptx_ctx* ctx, const char* gltf_path, const ptx_load_opts* opts /* NULL = defaults */,
+                        ptx_scene** out);
+
+/* Same, from caller-provided arrays (procedural scenes, or a host that did its own parsing).
+ * Models are given in the order the reference's renderer::intersect would visit them. */
+typedef struct ptx_scene_desc {
+	uint32_t n_models;
+	const float* model_xform;    /* [n_models][12]: origin(3), basis.x(3), basis.y(3), basis.z(3) — scene::transform */
+	const int32_t* model_surf;   /* [n_models][2]: first surface, surface count — scene::model::surfaces */
+	uint32_t n_surfaces;
+	const int32_t* surf_range;   /* [n_surfaces][4]: first vertex, vertex count, first triangle, triangle count */
+	const float* vertices;       /* [.][11]: position(3) tex_coord(2) normal(3) tangent(3) — core::vertex */
+	const uint32_t* triangles;   /* [.][3]: mesh-local vertex ids — core::mesh::triangles */
+	const float* materials;      /* [n_surfaces][11]: albedo(3) opacity roughness metallic emissive(3) ior shadow_catcher */
+	const float* camera;         /* [13]: origin(3) basis(9) vertical fov (radians) */
+	const float* sun;            /* NULL, or [13]: basis(9) energy(3) angular_radius — scene::sun_light */
+} ptx_scene_desc;
+int ptx_scene_from_arrays(ptx_ctx* ctx, const ptx_scene_desc* desc, ptx_scene** out);
+void ptx_scene_destroy(ptx_scene* scene);
+
+typedef struct ptx_scene_info {
+	uint32_t n_models, n_surfaces, n_vertices, n_triangles;
+	uint32_t n_kd_nodes;      /* flattened 8-byte nodes (branches + leaves) */
+	uint32_t n_kd_refs;       /* leaf triangle references */
+	uint32_t kd_max_depth;
+	uint32_t has_sun;
+	uint32_t geometry_bytes;  /* nodes + refs + triangle records: what the kernels stage through LDS */
+	uint32_t lds_resident;    /* 1 when geometry_bytes fits one CU's LDS and the LDS kernels are used */
+} ptx_scene_info;
+int ptx_scene_get_info(const ptx_scene* scene, ptx_scene_info* info);
+
+/* Host copies of the flattened arrays (tests, tooling). Returns the element count; dst may be NULL
+ * to query it. Element layouts are documented in DESIGN.md §"Data layout". */
+typedef enum ptx_array {
+	PTX_ARR_MODEL_XFORM = 0,  /* float[n_models][12] */
+	PTX_ARR_MODEL_AABB = 1,   /* float[n_models][6]  */
+	PTX_ARR_MODEL_SURF = 2,   /* int32[n_models][2]  */
+	PTX_ARR_SURF_RANGE = 3,   /* int32[n_surfaces][8]: v0,nv,t0,nt,kd_root,n_nodes,ref0,n_refs */
+	PTX_ARR_MESH_AABB = 4,    /* float[n_surfaces][6] */
+	PTX_ARR_VERTICES = 5,     /* float[n_vertices][11] */
+	PTX_ARR_TRIANGLES = 6,    /* uint32[n_triangles][3] */
+	PTX_ARR_MATERIALS = 7,    /* float[n_surfaces][11] */
+	PTX_ARR_KD_NODES = 8,     /* uint32[n_kd_nodes][2]  (packed device nodes) */
+	PTX_ARR_KD_REFS = 9,      /* uint32[n_kd_refs]      (global triangle ids) */
+	PTX_ARR_CAMERA = 10,      /* float[14]: origin basis fov tan_half_fov */
+	PTX_ARR_SUN = 11,         /* float[13] or empty */
+	PTX_ARR_MODEL_NAMES = 12  /* char[]: '\n'-separated entity names in visit order */
+} ptx_array;
+int64_t ptx_scene_get_array(const ptx_scene* scene, ptx_array which, void* dst, size_t dst_bytes);
+
+/* ---- tile worker --------------------------------------------------------------------------------
+ * Replaces core::renderer::render() (LIB/core/renderer.hpp:36, renderer.cpp:334-428) and the worker's
+ * staged pipeline (src/processors/worker/worker.hpp:27-41): renders samples [sample0, sample0+spp) of
+ * the pixel rectangle [x0,x0+w) x [y0,y0+h) of a W x H image and ADDS the per-pixel radiance SUMS
+ * (not means) into accum_rgba[h][w][4] (float32; alpha accumulates 1 per sample, as renderer.cpp:398).
+ * The fields mirror core::renderer's public fields (renderer.hpp:21-33) with the same defaults.
+ * Random numbers are a counter-based Philox4x32-10 stream keyed by (seed, pixel y*W+x, sample index,
+ * depth, draw), so any tiling / sample split / GPU count gives the same per-sample radiance. */
+typedef struct ptx_render_cfg {
+	uint32_t W, H;          /* renderer::resolution (1920 x 1080) */
+	uint32_t spp;           /* renderer::sample_count */
+	uint32_t bounces;       /* renderer::bounce_count (4) */
+	float env[3];           /* renderer::environment_factor (1,1,1) */
+	uint32_t seed_lo, seed_hi;
+	uint32_t x0, y0, w, h;  /* tile; w = h = 0 means the whole image */
+	uint32_t sample0;       /* first sample index */
+	uint32_t spp_per_pass;  /* 0 = library default; samples of every pixel traced per kernel launch */
+} ptx_render_cfg;
+typedef struct ptx_render_stats {
+	uint64_t rays;          /* closest-hit + shadow queries = renderer::intersect calls (renderer.cpp:441,509) */
+	uint64_t samples;       /* camera paths = trace() root calls */
+	uint64_t passes;        /* kernel launches of the integrator */
+	double kernel_ms;       /* HIP-event time of the integrator kernels on the context stream */
+} ptx_render_stats;
+/* accum_rgba: device or host pointer. stats may be NULL (no device->host sync is then forced). */
+int ptx_render(ptx_scene* scene, const ptx_render_cfg* cfg, float* accum_rgba, ptx_render_stats* stats);
+
+/* Batch form of renderer::intersect (renderer.cpp:645-725) / distributed_scene::intersect
+ * (src/scene/scene.hpp:20-21): the unit the host's INTERSECT stage queue would call.
+ * Rays are SoA; directions are used as given (the reference normalises on construction, ray.cpp:6-8,
+ * so pass unit vectors). All pointers device or host (all of one kind). */
+typedef struct ptx_rays {
+	const float *ox, *oy, *oz, *dx, *dy, *dz;
+} ptx_rays;
+typedef struct ptx_hits {
+	float* distance;    /* world-space hit distance; -1 = miss (model::intersection::distance, model.hpp:21) */
+	int32_t* surface;   /* global surface (primitive) id, -1 = miss */
+	int32_t* triangle;  /* triangle index within the surface's mesh */
+	float *b0, *b1, *b2;            /* barycentrics (alpha, beta, gamma) — triangle.cpp:185-189 */
+	float *px, *py, *pz;            /* world position        (may be NULL as a group of three) */
+	float *nx, *ny, *nz;            /* shading normal = intersect_result::get_normal(), renderer.cpp:430-435 (may be NULL) */
+	float *u, *v;                   /* interpolated tex_coord (may be NULL) */
+} ptx_hits;
+int ptx_intersect_batch(ptx_scene* scene, const ptx_rays* rays, size_t n, const ptx_hits* hits);
+
+/* ---- image write --------------------------------------------------------------------------------
+ * Replaces the tonemap + image::write loop of renderer.cpp:409-424 (core::tonemap_approx_aces,
+ * LIB/core/utils.hpp:29-36; image::image::write, LIB/image/image.cpp:143-154): divides the sums by
+ * `spp`, applies ACES, sRGB (pow 1/2.2) and quantises to RGBA8 row-major. accum/rgba8 device or host. */
+int ptx_tonemap_encode(ptx_ctx* ctx, const float* accum_rgba, uint32_t W, uint32_t H, uint32_t spp, uint8_t* rgba8);
+/* Replaces image::image::save_to_memory_png (LIB/image/image.cpp:111-122). Host memory only.
+ * *png is malloc'ed; release with ptx_free. Decoded pixels are exact; the byte stream is zlib's, not stb's. */
+int ptx_encode_png(const uint8_t* rgba8, uint32_t W, uint32_t H, uint8_t** png, size_t* png_bytes);
+void ptx_free(void* p);
+
+/* ---- multi-GPU ----------------------------------------------------------------------------------
+ * The reference's planned fan-in (SNS/SQS, never implemented: src/models/work_info.hpp:22-23) is replaced
+ * by ONE sum-reduce of the float accumulation buffer. The library does not own a communicator:
+ * torch.distributed (backend "nccl" = RCCL over xGMI) reduces the device buffer ptx_render filled; see
+ * INTEGRATION.md. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTX_H */

@@ -31,6 +31,12 @@ def gold_mean():
 
 
 @pytest.fixture(scope="session")
+def ptx():
+    import importlib
+    return importlib.import_module("distributed-path-tracer_amd")
+
+
+@pytest.fixture(scope="session")
 def ora():
     from oracle import pt_oracle
     pt_oracle.lib()

@@ -1,0 +1,136 @@
+"""Product host logic on CPU (no GPU, no compute calls): the C-ABI library loads and exports every
+symbol include/ptx.h declares; the product's own glTF loader / AABB / SAH KD builder / flattener
+reproduce the UNMODIFIED reference's scene (tests/golden/cornell_scene.npz); error behaviour."""
+import ctypes as C
+import io
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CORNELL
+
+
+def test_library_exports_every_declared_symbol(ptx):
+    L = ptx.lib()
+    names = ptx.declared_symbols()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/ptx.h but not exported"
+    assert b"gfx950" in L.ptx_version()
+
+
+@pytest.fixture(scope="module")
+def host_scene(ptx):
+    return ptx.Scene.load_gltf(None, CORNELL)   # ctx=None: host-only scene
+
+
+def test_loader_matches_reference(ptx, host_scene, gold_scene):
+    s, g = host_scene, gold_scene
+    assert s.array(ptx.ARR_MODEL_NAMES) == bytes(g["model_names"]).decode().split()
+    np.testing.assert_array_equal(s.array(ptx.ARR_MODEL_XFORM), g["model_xform"])
+    np.testing.assert_array_equal(s.array(ptx.ARR_MODEL_SURF), g["model_surf"])
+    np.testing.assert_array_equal(s.array(ptx.ARR_SURF_RANGE)[:, :4], g["surf_range"][:, :4])
+    np.testing.assert_array_equal(s.array(ptx.ARR_VERTICES), g["vertices"])
+    np.testing.assert_array_equal(s.array(ptx.ARR_TRIANGLES), g["triangles"])
+    np.testing.assert_array_equal(s.array(ptx.ARR_MATERIALS), g["materials"])
+    np.testing.assert_array_equal(s.array(ptx.ARR_CAMERA), g["camera"])
+    assert s.array(ptx.ARR_SUN).size == 0
+    np.testing.assert_array_equal(s.array(ptx.ARR_MODEL_AABB), g["model_aabb"])
+    np.testing.assert_array_equal(s.array(ptx.ARR_MESH_AABB), g["mesh_aabb"])
+
+
+def unpack_tree(nodes, refs, root):
+    """Packed breadth-first device nodes -> pre-order lists, the order the golden dump uses."""
+    out = []
+    def walk(i):
+        w0, w1 = int(nodes[i, 0]), int(nodes[i, 1])
+        kind = w1 & 3
+        if kind == 3:
+            cnt = w1 >> 2
+            out.append(("leaf", tuple(int(r) for r in refs[w0:w0 + cnt])))
+            return
+        hl, hr, first = bool(w1 & 4), bool(w1 & 8), w1 >> 4
+        out.append(("branch", kind, w0, hl, hr))
+        if hl:
+            walk(first)
+        if hr:
+            walk(first + (1 if hl else 0))
+    import sys
+    sys.setrecursionlimit(10000)
+    walk(root)
+    return out
+
+
+def gold_tree(g, s):
+    k0, nk, r0, nr = (int(v) for v in g["surf_range"][s, 4:8])
+    t0 = int(g["surf_range"][s, 2])
+    out = []
+    for i in range(k0, k0 + nk):   # the dump is already pre-order
+        if g["kd_type"][i] == 1:
+            f, c = int(g["kd_first"][i]), int(g["kd_count"][i])
+            out.append(("leaf", tuple(int(r) + t0 for r in g["kd_refs"][f:f + c])))
+        else:
+            out.append(("branch", int(g["kd_axis"][i]), int(g["kd_split"][i:i + 1].view(np.uint32)[0]),
+                        bool(g["kd_left"][i] >= 0), bool(g["kd_right"][i] >= 0)))
+    return out
+
+
+def test_kd_trees_have_the_reference_topology(ptx, host_scene, gold_scene):
+    nodes = host_scene.array(ptx.ARR_KD_NODES)
+    refs = host_scene.array(ptx.ARR_KD_REFS)
+    rng = host_scene.array(ptx.ARR_SURF_RANGE)
+    info = host_scene.info()
+    assert info["n_kd_nodes"] == len(gold_scene["kd_type"]) and info["n_kd_refs"] == len(gold_scene["kd_refs"])
+    assert info["kd_max_depth"] == gold_scene["kd_depth"].max()
+    for s in range(info["n_surfaces"]):
+        assert rng[s, 5] == gold_scene["surf_range"][s, 5] and rng[s, 7] == gold_scene["surf_range"][s, 7]
+        assert unpack_tree(nodes, refs, int(rng[s, 4])) == gold_tree(gold_scene, s)
+    assert info["lds_resident"] == 1 and info["geometry_bytes"] <= 160 * 1024
+
+
+def test_from_arrays_equals_gltf_load(ptx, host_scene, gold_scene):
+    g = gold_scene
+    s2 = ptx.Scene.from_arrays(None, g["model_xform"], g["model_surf"], g["surf_range"], g["vertices"], g["triangles"],
+                               g["materials"], g["camera"])
+    for a in (ptx.ARR_KD_NODES, ptx.ARR_KD_REFS, ptx.ARR_MESH_AABB, ptx.ARR_MODEL_AABB, ptx.ARR_SURF_RANGE, ptx.ARR_CAMERA):
+        np.testing.assert_array_equal(s2.array(a), host_scene.array(a))
+
+
+def test_error_behaviour(ptx, host_scene, tmp_path):
+    with pytest.raises(ptx.PtxError) as e:
+        ptx.Scene.load_gltf(None, str(tmp_path / "missing.gltf"))
+    assert e.value.code == ptx.ERR_IO
+    bad = tmp_path / "bad.gltf"
+    bad.write_text("{ not json")
+    with pytest.raises(ptx.PtxError) as e:
+        ptx.Scene.load_gltf(None, str(bad))
+    assert e.value.code == ptx.ERR_PARSE
+    # renderer.cpp:73-74: "Scene does not contain camera #i."
+    with pytest.raises(ptx.PtxError) as e:
+        ptx.Scene.load_gltf(None, CORNELL, camera_index=3)
+    assert e.value.code == ptx.ERR_NO_CAMERA and "camera #3" in str(e.value)
+    # GPU work on a host-only scene must fail loudly, never fall back
+    with pytest.raises(ptx.PtxError) as e:
+        host_scene.render(8, 8, 1, 1)
+    assert e.value.code == ptx.ERR_NO_DEVICE
+    with pytest.raises(ptx.PtxError) as e:
+        host_scene.intersect(np.zeros((1, 3), np.float32), np.array([[0, 0, 1]], np.float32))
+    assert e.value.code == ptx.ERR_NO_DEVICE
+
+
+def test_png_encode_roundtrip(ptx):
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    png = ptx.encode_png(img)
+    back = np.array(Image.open(io.BytesIO(png)))
+    np.testing.assert_array_equal(back, img)
+
+
+def test_reference_png_fixture_decodes(gold_vec):
+    # the deterministic PNG written by the reference's own renderer::render is a valid 64x64 RGBA image
+    from PIL import Image
+    from conftest import GOLD
+    im = np.array(Image.open(os.path.join(GOLD, "cornell_ref_64x64_16spp_4b.png")))
+    assert im.shape == (64, 64, 4) and (im[..., 3] == 255).all()
