@@ -11,9 +11,11 @@ and raises PtxError when the library or a GPU is missing.
 The directory name contains '-', so import it with importlib:
     ptx = importlib.import_module("distributed-path-tracer_amd")
 """
+import atexit
 import ctypes as C
 import os
 import re
+import weakref
 
 import numpy as np
 
@@ -70,6 +72,17 @@ class Hits(C.Structure):
 
 
 _lib = None
+_live = weakref.WeakSet()   # scenes and contexts still open; closed before interpreter teardown (atexit)
+                            # so that no HIP call is made after the HIP runtime's own static destructors ran
+
+
+@atexit.register
+def _close_all():
+    for o in sorted(list(_live), key=lambda x: isinstance(x, Context)):   # scenes first, then contexts
+        try:
+            o.close()
+        except Exception:
+            pass
 
 
 def declared_symbols():
@@ -79,12 +92,32 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(ptx_[a-z_0-9]+)\s*\(", txt)))
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 (+ HSA runtime) and a second
+    copy from /opt/rocm in the same process leaves whichever initialises second without a GPU. When torch is
+    installed, load ITS runtime first so that libptx_hip.so's DT_NEEDED libamdhip64.so.7 binds to the same one,
+    whatever the import order. (torch itself is not imported here.)"""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def lib():
     """Load libptx_hip.so. Raises (never falls back) when it is not built."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise PtxError(ERR_NO_DEVICE, f"{LIB_PATH} is not built; run __graft_entry__.build() — there is no fallback path")
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.ptx_last_error.restype = C.c_char_p
         L.ptx_version.restype = C.c_char_p
@@ -133,6 +166,7 @@ class Context:
         _check(lib().ptx_ctx_create(device, C.byref(h)))
         self.h = h
         self.device = device
+        _live.add(self)
 
     @property
     def stream(self):
@@ -171,6 +205,7 @@ class Scene:
     def __init__(self, handle, ctx):
         self.h = handle
         self.ctx = ctx
+        _live.add(self)
 
     @classmethod
     def load_gltf(cls, ctx, path, camera_index=0, sun_light_index=0):

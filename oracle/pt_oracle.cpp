@@ -278,7 +278,7 @@ static void mesh_finish(mesh& m) {
 
 struct mesh_hit { float t = -1; v3 bary{0, 0, 0}; uint32_t index = 0; };
 
-struct trav_stats { uint64_t branches = 0, leaves = 0, tris = 0, pushes = 0, mesh_tests = 0, model_tests = 0; };
+struct trav_stats { uint64_t branches = 0, leaves = 0, tris = 0, pushes = 0, mesh_tests = 0, model_tests = 0; uint64_t depth_hist[32] = {0}; };
 
 // mesh::intersect — mesh.cpp:300-405
 static mesh_hit mesh_intersect(const mesh& m, const ray& r, trav_stats* st) {
@@ -288,6 +288,8 @@ static mesh_hit mesh_intersect(const mesh& m, const ray& r, trav_stats* st) {
 	struct ent { int node; float mn, mx; };
 	ent stack[64];
 	int sp = 0;
+	int max_sp = 0;   // diagnostics only: deepest simultaneous number of PENDING entries (root excluded)
+	struct depth_rec { trav_stats* st; int* m; ~depth_rec() { if (st) st->depth_hist[*m < 31 ? *m : 31]++; } } rec{st, &max_sp};
 	stack[sp++] = {0, bh.nr, bh.fr};
 	while (sp > 0) {
 		ent e = stack[--sp];
@@ -304,7 +306,7 @@ static mesh_hit mesh_intersect(const mesh& m, const ray& r, trav_stats* st) {
 			if (split_dist < 0 || split_dist > max_dist) node = first;
 			else if (split_dist < min_dist) node = second;
 			else {
-				if (second >= 0) { stack[sp++] = {second, split_dist, max_dist}; if (st) st->pushes++; }
+				if (second >= 0) { stack[sp++] = {second, split_dist, max_dist}; if (st) st->pushes++; if (sp > max_sp) max_sp = sp; }
 				node = first;
 				max_dist = split_dist;
 			}
@@ -755,7 +757,7 @@ void ora_model_intersect(void* p, int mdl, size_t n, const float* rays, float* o
 	}
 }
 // out[n][14] = position(3) uv(2) normal(3) tangent(3) shading_normal(3); idx = surface id or -1
-void ora_scene_intersect(void* p, size_t n, const float* rays, float* out, int* idx, uint64_t* stats /*[6] or null*/) {
+void ora_scene_intersect(void* p, size_t n, const float* rays, float* out, int* idx, uint64_t* stats /*[6+32] or null*/) {
 	const scene_t& s = *(scene_t*)p;
 	trav_stats st;
 	for (size_t i = 0; i < n; i++) {
@@ -771,6 +773,7 @@ void ora_scene_intersect(void* p, size_t n, const float* rays, float* out, int* 
 	if (stats) {
 		stats[0] = st.model_tests; stats[1] = st.mesh_tests; stats[2] = st.branches;
 		stats[3] = st.leaves; stats[4] = st.tris; stats[5] = st.pushes;
+		for (int k = 0; k < 32; k++) stats[6 + k] = st.depth_hist[k];
 	}
 }
 // in[n][14] = n(3) o(3) i(3) u1 u2 rough cos_theta ior ; out[n][15] as in ref_harness.cpp "pbr_out"

