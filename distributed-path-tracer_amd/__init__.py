@@ -20,7 +20,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptx_hip.so")
+LIB_PATH = os.environ.get("PTX_LIB") or os.path.join(_HERE, "libptx_hip.so")  # PTX_LIB: experiment builds only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ptx.h")
 
 OK, ERR_INVALID, ERR_IO, ERR_PARSE, ERR_NO_CAMERA, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = range(8)

@@ -60,6 +60,18 @@ struct MaterialRec {
 	float metallic; float ior; uint32_t shadow_catcher; uint32_t tex_mask;
 };
 
+// ---- everything the SHADING phase needs about the surface that was hit, gathered per surface so that a
+// divergent lookup is 9 aligned 16-byte reads from one place (LDS when it fits): the owning model's
+// local->world transform and normal matrix, and the material. 144 B.
+struct ShadeRec {
+	float basis[9];   // model global basis, columns
+	float origin[3];
+	float nmat[9];    // transpose(inverse(basis)), columns
+	float pad[3];
+	MaterialRec mat;
+};
+static_assert(sizeof(ShadeRec) == 144, "ShadeRec layout");
+
 struct CameraRec { float origin[3]; float basis[9]; float fov; float tan_half_fov; };
 struct SunRec { float basis[9]; float energy[3]; float angular_radius; uint32_t present; };
 
@@ -78,6 +90,7 @@ struct FlatScene {
 	std::vector<ModelRec> models;
 	std::vector<SurfaceRec> surfaces;
 	std::vector<MaterialRec> materials;
+	std::vector<ShadeRec> shade;         // per surface
 	std::vector<KdNode> kd_nodes;
 	std::vector<uint32_t> kd_refs;       // global triangle ids
 	std::vector<TriRec> tris;
@@ -86,6 +99,7 @@ struct FlatScene {
 	SunRec sun{};
 	uint32_t kd_max_depth = 0;
 	bool any_texture = false;
+	bool any_alpha = false;              // some material can take the opacity / shadow-catcher pass-through branch
 
 	size_t geometry_bytes() const { return kd_nodes.size() * 8 + kd_refs.size() * 4 + tris.size() * 48; }
 };

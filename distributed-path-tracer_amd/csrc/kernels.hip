@@ -94,28 +94,48 @@ DEV float tri_test(V3 a, V3 b, V3 c, V3 o, V3 d, float& alpha, float& beta, floa
 	return dist;
 }
 
-struct MeshHit { float t; float b0, b1, b2; uint32_t tri; };
+struct MeshHit { float t; float b1, b2; uint32_t tri; };
 
-constexpr int kStack = 32;  // >= reference max depth 25 (+1): one push per level at most
+constexpr int kRegStack = 3;    // pending KD subtrees kept in registers (covers > 99 % of traversals)
+constexpr int kSpillStack = 24; // deeper entries go to a private array: the reference pushes at most one entry per
+                                // level and its trees are at most 26 levels deep (mesh.hpp:34, max_depth = 25)
+
+// geometry::aabb::intersect with the reciprocal direction hoisted: the same local ray is tested against the
+// model box and every surface box, and 1/dir has one value per ray whatever box it meets.
+DEV bool aabb_test_inv(const float* mn, const float* mx, V3 o, V3 inv, float& nr, float& fr) {
+	if (mn[0] > mx[0] || mn[1] > mx[1] || mn[2] > mx[2]) return false;
+	float ax = (mn[0] - o.x) * inv.x, ay = (mn[1] - o.y) * inv.y, az = (mn[2] - o.z) * inv.z;
+	float bx = (mx[0] - o.x) * inv.x, by = (mx[1] - o.y) * inv.y, bz = (mx[2] - o.z) * inv.z;
+	nr = pmax(pmax(pmin(ax, bx), pmin(ay, by)), pmin(az, bz));
+	fr = pmin(pmin(pmax(ax, bx), pmax(ay, by)), pmax(az, bz));
+	if (nr > fr) return false;
+	return fr >= 0;
+}
 
 // core::mesh::intersect — core/mesh.cpp:300-405: front-to-back stack traversal, returns at the first
 // leaf that yields a hit within [.., max_dist].
-DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, MeshHit& out, uint32_t* stk_node, float* stk_min,
-                       float* stk_max) {
+// Stack entries are (node, min_dist) only: the max_dist the reference stores with an entry is always the
+// min_dist of the entry beneath it (each push hands its old max_dist to the pushed subtree and continues
+// with max_dist = split_dist = the pushed min_dist), and the AABB exit distance for the bottom one.
+DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, MeshHit& out, uint32_t* spill_node, float* spill_min) {
 	float nr, fr;
-	if (!aabb_test(sf.bmin, sf.bmax, o, d, nr, fr)) return false;
+	if (!aabb_test_inv(sf.bmin, sf.bmax, o, inv, nr, fr)) return false;
 	int sp = 0;
+	uint32_t n0 = 0, n1 = 0, n2 = 0;  // register stack: entry 0 is the top
+	float m0 = 0, m1 = 0, m2 = 0;
 	uint32_t node = sf.kd_root;
 	float min_dist = nr, max_dist = fr;
-	bool have = true;  // a node to descend from
+	bool have = true;
 	for (;;) {
 		if (!have) {
 			if (sp == 0) return false;
 			sp--;
-			node = stk_node[sp]; min_dist = stk_min[sp]; max_dist = stk_max[sp];
+			node = n0; min_dist = m0;
+			n0 = n1; m0 = m1; n1 = n2; m1 = m2;
+			if (sp >= kRegStack) { n2 = spill_node[sp - kRegStack]; m2 = spill_min[sp - kRegStack]; }
+			max_dist = sp > 0 ? m0 : fr;
 		}
 		have = false;
-		// descend to a leaf (or off the tree through a missing child)
 		bool valid = true;
 		uint2 nd = g.nodes[node];
 		while ((nd.y & 3u) != KD_LEAF) {
@@ -133,7 +153,11 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, MeshHit&
 			if (split_dist < 0 || split_dist > max_dist) { next = first; has_next = has_first; }
 			else if (split_dist < min_dist) { next = second; has_next = has_second; }
 			else {
-				if (has_second && sp < kStack) { stk_node[sp] = second; stk_min[sp] = split_dist; stk_max[sp] = max_dist; sp++; }
+				if (has_second && sp < kRegStack + kSpillStack) {
+					if (sp >= kRegStack) { spill_node[sp - kRegStack] = n2; spill_min[sp - kRegStack] = m2; }
+					n2 = n1; m2 = m1; n1 = n0; m1 = m0; n0 = second; m0 = split_dist;
+					sp++;
+				}
 				next = first; has_next = has_first;
 				max_dist = split_dist;
 			}
@@ -144,41 +168,43 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, MeshHit&
 		if (!valid) continue;
 		// leaf: nearest triangle with t <= max_dist; ties keep the first (mesh.cpp:381-389)
 		uint32_t first_ref = nd.x, count = nd.y >> 2;
-		float best_t = -1.0f, bb0 = 0, bb1 = 0, bb2 = 0;
+		float best_t = -1.0f, bb1 = 0, bb2 = 0;
 		uint32_t best_tri = 0;
 		for (uint32_t i = 0; i < count; i++) {
 			uint32_t ti = g.refs[first_ref + i];
 			float4 A = g.tris[3 * ti], B = g.tris[3 * ti + 1], C = g.tris[3 * ti + 2];
 			float al, be, ga;
 			float t = tri_test(mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), mk(C.x, C.y, C.z), o, d, al, be, ga);
-			if (t >= 0 && t <= max_dist && (t < best_t || !(best_t >= 0))) { best_t = t; bb0 = al; bb1 = be; bb2 = ga; best_tri = ti; }
+			if (t >= 0 && t <= max_dist && (t < best_t || !(best_t >= 0))) { best_t = t; bb1 = be; bb2 = ga; best_tri = ti; }
 		}
 		if (!(best_t >= 0)) continue;
-		out.t = best_t; out.b0 = bb0; out.b1 = bb1; out.b2 = bb2; out.tri = best_tri;
+		out.t = best_t; out.b1 = bb1; out.b2 = bb2; out.tri = best_tri;
 		return true;
 	}
 }
 
-struct SceneHit { float dist; int model; int surface; uint32_t tri; float b0, b1, b2; };
+// Closest hit record: what the shading phase needs to rebuild everything else.
+// alpha is not stored: it is 1 - beta - gamma (triangle.cpp:185), recomputed with the same two subtractions.
+struct SceneHit { float dist; int surface; uint32_t tri; float b1, b2; };
 
 // renderer::intersect (core/renderer.cpp:645-671) over scene::model::intersect (scene/model.cpp:20-72)
-DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& best, uint32_t* stk_node, float* stk_min,
-                        float* stk_max) {
+DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& best, uint32_t* spill_node, float* spill_min) {
 	best.dist = -1.0f;
-	best.model = -1;
+	best.surface = -1;
 	for (int m = 0; m < S.n_models; m++) {
 		const ModelRec& M = S.models[m];
 		// ray::transform(inverse): origin' = inv*o, dir' = normalize(inv.basis*dir)  (geometry/ray.cpp:10-15)
 		V3 lo = mulmv(M.inv_basis, o) + mk(M.inv_origin[0], M.inv_origin[1], M.inv_origin[2]);
 		V3 ld = normalize(mulmv(M.inv_basis, d));
+		V3 inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
 		float nr, fr;
-		if (!aabb_test(M.bmin, M.bmax, lo, ld, nr, fr)) continue;
+		if (!aabb_test_inv(M.bmin, M.bmax, lo, inv, nr, fr)) continue;
 		MeshHit nearest;
 		nearest.t = -1.0f;
 		int hit_surface = -1;
 		for (int s = 0; s < M.n_surfaces; s++) {
 			MeshHit h;
-			if (!mesh_traverse(g, S.surfaces[M.first_surface + s], lo, ld, h, stk_node, stk_min, stk_max)) continue;
+			if (!mesh_traverse(g, S.surfaces[M.first_surface + s], lo, ld, inv, h, spill_node, spill_min)) continue;
 			if (h.t < nearest.t || !(nearest.t >= 0)) { nearest = h; hit_surface = M.first_surface + s; }
 		}
 		if (!(nearest.t >= 0)) continue;
@@ -186,29 +212,28 @@ DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& 
 		float wd = length(mulmv(M.basis, ld * nearest.t));
 		if (!(wd >= 0)) continue;
 		if (wd < best.dist || !(best.dist >= 0)) {
-			best.dist = wd; best.model = m; best.surface = hit_surface; best.tri = nearest.tri;
-			best.b0 = nearest.b0; best.b1 = nearest.b1; best.b2 = nearest.b2;
+			best.dist = wd; best.surface = hit_surface; best.tri = nearest.tri; best.b1 = nearest.b1; best.b2 = nearest.b2;
 		}
 	}
-	return best.model >= 0;
+	return best.surface >= 0;
 }
 
 struct Surf { V3 pos, nrm, tan; float u, v; };
 
 // attribute interpolation of renderer::intersect — core/renderer.cpp:688-715
-DEV void hit_attributes(const DevScene& S, const Geom& g, const SceneHit& h, Surf& out) {
-	const ModelRec& M = S.models[h.model];
-	float4 A = g.tris[3 * h.tri], B = g.tris[3 * h.tri + 1], C = g.tris[3 * h.tri + 2];
+DEV void hit_attributes(const DevScene& S, const Geom& g, const ShadeRec& R, uint32_t tri, float b1, float b2, Surf& out) {
+	const float b0 = 1 - b1 - b2;
+	float4 A = g.tris[3 * tri], B = g.tris[3 * tri + 1], C = g.tris[3 * tri + 2];
 	uint32_t ia = __float_as_uint(A.w), ib = __float_as_uint(B.w), ic = __float_as_uint(C.w);
 	float4 a0 = S.vattr[2 * ia], a1 = S.vattr[2 * ia + 1];
-	float4 b0 = S.vattr[2 * ib], b1 = S.vattr[2 * ib + 1];
 	float4 c0 = S.vattr[2 * ic], c1 = S.vattr[2 * ic + 1];
-	V3 lp = mk(A.x, A.y, A.z) * h.b0 + mk(B.x, B.y, B.z) * h.b1 + mk(C.x, C.y, C.z) * h.b2;
-	out.pos = mulmv(M.basis, lp) + mk(M.origin[0], M.origin[1], M.origin[2]);
-	out.u = a0.w * h.b0 + b0.w * h.b1 + c0.w * h.b2;
-	out.v = a1.w * h.b0 + b1.w * h.b1 + c1.w * h.b2;
-	out.nrm = normalize(mulmv(M.nmat, mk(a0.x, a0.y, a0.z) * h.b0 + mk(b0.x, b0.y, b0.z) * h.b1 + mk(c0.x, c0.y, c0.z) * h.b2));
-	out.tan = normalize(mulmv(M.nmat, mk(a1.x, a1.y, a1.z) * h.b0 + mk(b1.x, b1.y, b1.z) * h.b1 + mk(c1.x, c1.y, c1.z) * h.b2));
+	float4 e0 = S.vattr[2 * ib], e1 = S.vattr[2 * ib + 1];
+	V3 lp = mk(A.x, A.y, A.z) * b0 + mk(B.x, B.y, B.z) * b1 + mk(C.x, C.y, C.z) * b2;
+	out.pos = mulmv(R.basis, lp) + mk(R.origin[0], R.origin[1], R.origin[2]);
+	out.u = a0.w * b0 + e0.w * b1 + c0.w * b2;
+	out.v = a1.w * b0 + e1.w * b1 + c1.w * b2;
+	out.nrm = normalize(mulmv(R.nmat, mk(a0.x, a0.y, a0.z) * b0 + mk(e0.x, e0.y, e0.z) * b1 + mk(c0.x, c0.y, c0.z) * b2));
+	out.tan = normalize(mulmv(R.nmat, mk(a1.x, a1.y, a1.z) * b0 + mk(e1.x, e1.y, e1.z) * b1 + mk(c1.x, c1.y, c1.z) * b2));
 }
 
 // intersect_result::get_normal (renderer.cpp:430-435) with material::get_normal = (0,0,1) (no normal map)
@@ -324,25 +349,31 @@ DEV void camera_ray(const DevScene& S, const RenderParams& P, uint32_t x, uint32
 // ------------------------------------------------------------------------------------ one path vertex
 // renderer::trace (core/renderer.cpp:437-643) in iterative throughput form (DESIGN.md "Estimator"):
 //   L += T * (direct + emissive);  T *= clamp(brdf / max(pdf, eps), 0, 1);  next ray.
-// Returns true when the path continues with (o, d) updated. `rays` counts renderer::intersect calls.
-DEV bool path_vertex(const DevScene& S, const Geom& g, const RenderParams& P, uint32_t pixel, uint32_t sample, uint32_t depth,
-                     V3& o, V3& d, V3& T, V3& L, uint32_t& rays, uint32_t* stk_node, float* stk_min, float* stk_max) {
+// `h` is the closest hit of (o, d) found by the extend phase. Returns true when the path continues with
+// (o, d) updated. SUN / ALPHA select the code that needs a second traversal from inside the shading phase
+// (sun shadow rays; opacity / shadow-catcher pass-through): scenes without them get a kernel without it.
+template <bool SUN, bool ALPHA>
+DEV bool shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, const RenderParams& P, uint32_t pixel, uint32_t sample,
+                      uint32_t depth, SceneHit h, V3& o, V3& d, V3& T, V3& L, uint32_t& rays, uint32_t* spill_node, float* spill_min) {
 	uint32_t pass = 0;
 	for (;;) {
-		SceneHit h;
-		rays++;
-		if (!scene_traverse(S, g, o, d, h, stk_node, stk_min, stk_max)) {
+		if (h.surface < 0) {
 			L = L + T * mk(P.env[0], P.env[1], P.env[2]);  // miss: environment_factor (renderer.cpp:443-451)
 			return false;
 		}
+		const ShadeRec& R = shade[h.surface];
 		Surf sf;
-		hit_attributes(S, g, h, sf);
-		const MaterialRec& mt = S.materials[h.surface];
+		hit_attributes(S, g, R, h.tri, h.b1, h.b2, sf);
+		const MaterialRec& mt = R.mat;
 		V3 albedo = mk(mt.albedo[0], mt.albedo[1], mt.albedo[2]);
-		float roughness = mt.roughness, metallic = mt.metallic, opacity = mt.opacity;
+		float roughness = mt.roughness, metallic = mt.metallic;
 		float4 rnd = draws(P, pixel, sample, depth, pass, BLOCK_SURFACE);  // x opacity, y lobe, z/w BSDF sample
 
-		bool pass_through = !(opacity == 1.0f || fabsf(opacity - 1.0f) < kEps) && rnd.x > opacity;  // renderer.cpp:466-472
+		bool pass_through = false;
+		if constexpr (ALPHA) {
+			float opacity = mt.opacity;
+			pass_through = !(opacity == 1.0f || fabsf(opacity - 1.0f) < kEps) && rnd.x > opacity;  // renderer.cpp:466-472
+		}
 		V3 normal = mk(0, 0, 0), outcoming = -d;
 		float spec_prob = 0;
 		if (!pass_through) {
@@ -353,35 +384,41 @@ DEV bool path_vertex(const DevScene& S, const Geom& g, const RenderParams& P, ui
 			spec_prob = pmax(spec_prob, metallic);
 		}
 		V3 direct_out = mk(0, 0, 0);
-		if (!pass_through && S.sun.present) {                                // renderer.cpp:498-564
-			float4 sr = draws(P, pixel, sample, depth, pass, BLOCK_SUN);
-			V3 din = mulmv(S.sun.basis, mk(0, 0, 1));
-			din = rand_cone_vec(sr.x, cosf(sr.y * S.sun.angular_radius), din);
-			if (dot(normal, din) > 0) {
-				V3 so = sf.pos + din * kEps, sd = normalize(din);
-				SceneHit sh;
-				rays++;
-				bool shadowed = scene_traverse(S, g, so, sd, sh, stk_node, stk_min, stk_max);
-				bool catcher = mt.shadow_catcher && depth == 0;
-				if (!shadowed) {
-					if (catcher) pass_through = true;                        // lit shadow catcher behaves as fully transparent
-					else {
-						float pdf_unused;
-						V3 brdf = eval_brdf(normal, outcoming, din, albedo, roughness, metallic, spec_prob, pdf_unused);
-						V3 e = mk(S.sun.energy[0], S.sun.energy[1], S.sun.energy[2]);
-						float pdf = lerpf(1.0f, 1.0f, spec_prob);
-						V3 v = brdf * e / pmax(pdf, kEps);
-						direct_out = mk(clampf(v.x, 0, e.x), clampf(v.y, 0, e.y), clampf(v.z, 0, e.z));
-					}
-				} else if (catcher) return false;                            // shadowed catcher: black
+		if constexpr (SUN) {
+			if (!pass_through) {                                             // renderer.cpp:498-564
+				float4 sr = draws(P, pixel, sample, depth, pass, BLOCK_SUN);
+				V3 din = mulmv(S.sun.basis, mk(0, 0, 1));
+				din = rand_cone_vec(sr.x, cosf(sr.y * S.sun.angular_radius), din);
+				if (dot(normal, din) > 0) {
+					V3 so = sf.pos + din * kEps, sd = normalize(din);
+					SceneHit sh;
+					rays++;
+					bool shadowed = scene_traverse(S, g, so, sd, sh, spill_node, spill_min);
+					bool catcher = ALPHA && mt.shadow_catcher && depth == 0;
+					if (!shadowed) {
+						if (catcher) pass_through = true;                    // lit shadow catcher behaves as fully transparent
+						else {
+							float pdf_unused;
+							V3 brdf = eval_brdf(normal, outcoming, din, albedo, roughness, metallic, spec_prob, pdf_unused);
+							V3 e = mk(S.sun.energy[0], S.sun.energy[1], S.sun.energy[2]);
+							float pdf = lerpf(1.0f, 1.0f, spec_prob);
+							V3 v = brdf * e / pmax(pdf, kEps);
+							direct_out = mk(clampf(v.x, 0, e.x), clampf(v.y, 0, e.y), clampf(v.z, 0, e.z));
+						}
+					} else if (catcher) return false;                        // shadowed catcher: black
+				}
 			}
 		}
-		if (pass_through) {
-			o = sf.pos + d * kEps;
-			d = normalize(d);
-			pass++;
-			if (pass > 4096) return false;  // safety bound; the reference would recurse without limit
-			continue;
+		if constexpr (ALPHA) {
+			if (pass_through) {
+				o = sf.pos + d * kEps;
+				d = normalize(d);
+				pass++;
+				if (pass > 4096) return false;  // safety bound; the reference would recurse without limit
+				rays++;
+				scene_traverse(S, g, o, d, h, spill_node, spill_min);
+				continue;
+			}
 		}
 		V3 inc = (rnd.y < spec_prob) ? importance_specular(rnd.z, rnd.w, normal, outcoming, roughness)
 		                              : importance_diffuse(rnd.z, rnd.w, normal);
@@ -398,22 +435,29 @@ DEV bool path_vertex(const DevScene& S, const Geom& g, const RenderParams& P, ui
 }
 
 // ------------------------------------------------------------------------------------ LDS staging
+struct Staged { Geom g; const ShadeRec* shade; };
+
 template <bool LDS>
-DEV Geom stage_geometry(const DevScene& S, unsigned char* smem) {
-	if constexpr (!LDS) return {S.nodes, S.refs, S.tris};
+DEV Staged stage_geometry(const DevScene& S, unsigned char* smem) {
+	if constexpr (!LDS) return {{S.nodes, S.refs, S.tris}, S.shade};
 	else {
-		// [triangle records][KD nodes][leaf refs], each region a multiple of 16 B
+		// [triangle records][shade records][KD nodes][leaf refs], each region a multiple of 16 B
 		uint4* dst = reinterpret_cast<uint4*>(smem);
-		const uint32_t n_tri16 = S.n_tris * 3, n_node16 = (S.n_nodes + 1) / 2, n_ref16 = (S.n_refs + 3) / 4;
+		const uint32_t n_tri16 = S.n_tris * 3, n_shade16 = S.n_surfaces * 9, n_node16 = (S.n_nodes + 1) / 2, n_ref16 = (S.n_refs + 3) / 4;
 		const uint4* src_t = reinterpret_cast<const uint4*>(S.tris);
+		const uint4* src_s = reinterpret_cast<const uint4*>(S.shade);
 		const uint4* src_n = reinterpret_cast<const uint4*>(S.nodes);
 		const uint4* src_r = reinterpret_cast<const uint4*>(S.refs);
+		uint4* d_s = dst + n_tri16;
+		uint4* d_n = d_s + n_shade16;
+		uint4* d_r = d_n + n_node16;
 		for (uint32_t i = threadIdx.x; i < n_tri16; i += blockDim.x) dst[i] = src_t[i];
-		for (uint32_t i = threadIdx.x; i < n_node16; i += blockDim.x) dst[n_tri16 + i] = src_n[i];
-		for (uint32_t i = threadIdx.x; i < n_ref16; i += blockDim.x) dst[n_tri16 + n_node16 + i] = src_r[i];
+		for (uint32_t i = threadIdx.x; i < n_shade16; i += blockDim.x) d_s[i] = src_s[i];
+		for (uint32_t i = threadIdx.x; i < n_node16; i += blockDim.x) d_n[i] = src_n[i];
+		for (uint32_t i = threadIdx.x; i < n_ref16; i += blockDim.x) d_r[i] = src_r[i];
 		__syncthreads();
-		return {reinterpret_cast<const uint2*>(dst + n_tri16), reinterpret_cast<const uint32_t*>(dst + n_tri16 + n_node16),
-		        reinterpret_cast<const float4*>(dst)};
+		return {{reinterpret_cast<const uint2*>(d_n), reinterpret_cast<const uint32_t*>(d_r), reinterpret_cast<const float4*>(dst)},
+		        reinterpret_cast<const ShadeRec*>(d_s)};
 	}
 }
 
@@ -421,15 +465,20 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 
 // ------------------------------------------------------------------------------------ integrator kernel
 // One launch = `P.n_paths` camera paths (P.pass_spp samples of every tile pixel), all bounces.
-template <bool LDS>
+// Per wave and chunk of kChunk paths, every bounce is two sweeps over the wave's private ray stream:
+//   EXTEND: (generate or) load ray -> closest hit -> 16-byte hit record        (traversal state only in registers)
+//   SHADE : load ray + hit + path state -> BSDF, radiance, next ray -> compacted write (path state only)
+template <bool LDS, bool SUN, bool ALPHA>
 __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S, RenderParams P, PassBuffers B) {
-	const Geom g = stage_geometry<LDS>(S, g_smem);
+	const Staged st = stage_geometry<LDS>(S, g_smem);
+	const Geom g = st.g;
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave_slot = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	// wave-private ray stream: 2 buffers x 4 float4 arrays x kChunk entries
-	float4* qbase = B.queues + (size_t)wave_slot * (2u * 4u * kChunk);
-	uint32_t stk_node[kStack];
-	float stk_min[kStack], stk_max[kStack];
+	// wave-private streams: 2 ray buffers x 4 float4 arrays x kChunk entries, then 1 hit array
+	float4* qbase = B.queues + (size_t)wave_slot * (kQueueFloat4PerWave);
+	float4* hbuf = qbase + 2u * 4u * kChunk;
+	uint32_t spill_node[kSpillStack];
+	float spill_min[kSpillStack];
 	uint32_t rays = 0;
 
 	for (;;) {
@@ -444,33 +493,66 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S, RenderParams
 			float4* qin = qbase + (size_t)(depth & 1u) * (4u * kChunk);
 			float4* qout = qbase + (size_t)((depth + 1u) & 1u) * (4u * kChunk);
 			const bool last = depth + 1 == P.bounces;
+
+#ifdef PTX_STAMP
+			const unsigned long long t_a = __builtin_amdgcn_s_memtime();
+#endif
+			// ---------------- EXTEND
+			for (uint32_t base = 0; base < n_in; base += 64) {
+				const uint32_t i = base + lane;
+				if (i < n_in) {
+					V3 o, d;
+					if (depth == 0) {
+						const uint32_t id = (uint32_t)first + i;  // id within the pass: sample-major, pixel-minor
+						const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
+						const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
+						camera_ray(S, P, px, py, P.sample0 + s_local, o, d);
+						qin[i] = make_float4(o.x, o.y, o.z, __uint_as_float(id));
+						qin[kChunk + i] = make_float4(d.x, d.y, d.z, 1.0f);
+					} else {
+						float4 q0 = qin[i], q1 = qin[kChunk + i];
+						o = mk(q0.x, q0.y, q0.z);
+						d = mk(q1.x, q1.y, q1.z);
+					}
+					SceneHit h;
+					scene_traverse(S, g, o, d, h, spill_node, spill_min);
+					hbuf[i] = make_float4(__int_as_float(h.surface), __uint_as_float(h.tri), h.b1, h.b2);
+				}
+			}
+			rays += n_in > lane ? (n_in - lane + 63u) / 64u : 0u;  // rays this lane traced in the sweep
+			// the wave re-reads below what other lanes of this wave just wrote
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+#ifdef PTX_STAMP
+			const unsigned long long t_b = __builtin_amdgcn_s_memtime();
+#endif
+			// ---------------- SHADE + wave-level stream compaction
 			uint32_t n_out = 0;
 			for (uint32_t base = 0; base < n_in; base += 64) {
 				const uint32_t i = base + lane;
 				const bool active = i < n_in;
 				V3 o = {0, 0, 0}, d = {0, 0, 1}, T = {1, 1, 1}, L = {0, 0, 0};
 				uint32_t id = 0;
-				if (active) {
-					if (depth == 0) {
-						id = (uint32_t)first + i;  // id within the pass: sample-major, pixel-minor
-					} else {
-						float4 q0 = qin[i], q1 = qin[kChunk + i], q2 = qin[2 * kChunk + i], q3 = qin[3 * kChunk + i];
-						o = mk(q0.x, q0.y, q0.z); id = __float_as_uint(q0.w);
-						d = mk(q1.x, q1.y, q1.z); T = mk(q1.w, q2.x, q2.y);
-						L = mk(q2.z, q2.w, q3.x);
-					}
-				}
-				const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
-				const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
-				const uint32_t pixel = py * P.W + px, sample = P.sample0 + s_local;
 				bool alive = false;
 				if (active) {
-					if (depth == 0) camera_ray(S, P, px, py, sample, o, d);
-					alive = path_vertex(S, g, P, pixel, sample, depth, o, d, T, L, rays, stk_node, stk_min, stk_max);
+					float4 q0 = qin[i], q1 = qin[kChunk + i], hq = hbuf[i];
+					o = mk(q0.x, q0.y, q0.z); id = __float_as_uint(q0.w);
+					d = mk(q1.x, q1.y, q1.z);
+					if (depth != 0) {
+						float4 q2 = qin[2 * kChunk + i], q3 = qin[3 * kChunk + i];
+						T = mk(q1.w, q2.x, q2.y);
+						L = mk(q2.z, q2.w, q3.x);
+					}
+					SceneHit h;
+					h.dist = 0; h.surface = __float_as_int(hq.x); h.tri = __float_as_uint(hq.y); h.b1 = hq.z; h.b2 = hq.w;
+					const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
+					const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
+					alive = shade_vertex<SUN, ALPHA>(S, g, st.shade, P, py * P.W + px, P.sample0 + s_local, depth, h, o, d, T, L, rays,
+					                                 spill_node, spill_min);
 					if (last) alive = false;  // trace(0, ..) returns black: renderer.cpp:438-439
 					if (!alive) B.sample_rad[id] = make_float4(L.x, L.y, L.z, 1.0f);
 				}
-				// wave-level stream compaction: ballot + lane prefix count
 				const uint64_t mask = __ballot(alive);
 				if (alive) {
 					const uint32_t pos = n_out + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -482,9 +564,12 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S, RenderParams
 				n_out += (uint32_t)__popcll(mask);
 			}
 			n_in = n_out;
-			// the wave re-reads (next depth) what OTHER lanes of this wave just wrote
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef PTX_STAMP  // diagnostic build only: wave-cycles spent in each phase, summed over waves (never shipped)
+			const unsigned long long t_c = __builtin_amdgcn_s_memtime();
+			if (lane == 0) { atomicAdd(B.ray_counter + 1, t_b - t_a); atomicAdd(B.ray_counter + 2, t_c - t_b); }
+#endif
 		}
 	}
 	// ray counter: one atomic per wave
@@ -507,21 +592,22 @@ __global__ void k_resolve(const float4* __restrict__ sample_rad, float4* __restr
 // ------------------------------------------------------------------------------------ batch intersect
 template <bool LDS>
 __global__ void __launch_bounds__(kBlock) k_intersect_batch(DevScene S, IntersectArgs A) {
-	const Geom g = stage_geometry<LDS>(S, g_smem);
-	uint32_t stk_node[kStack];
-	float stk_min[kStack], stk_max[kStack];
+	const Staged st = stage_geometry<LDS>(S, g_smem);
+	const Geom g = st.g;
+	uint32_t spill_node[kSpillStack];
+	float spill_min[kSpillStack];
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (size_t)gridDim.x * blockDim.x) {
 		V3 o = mk(A.ox[i], A.oy[i], A.oz[i]), d = mk(A.dx[i], A.dy[i], A.dz[i]);
 		SceneHit h;
-		bool hit = scene_traverse(S, g, o, d, h, stk_node, stk_min, stk_max);
+		bool hit = scene_traverse(S, g, o, d, h, spill_node, spill_min);
 		A.distance[i] = hit ? h.dist : -1.0f;
 		A.surface[i] = hit ? h.surface : -1;
 		A.triangle[i] = hit ? (int32_t)(h.tri - S.surfaces[h.surface].tri_base) : -1;
-		A.b0[i] = hit ? h.b0 : 0.f; A.b1[i] = hit ? h.b1 : 0.f; A.b2[i] = hit ? h.b2 : 0.f;
+		A.b0[i] = hit ? 1 - h.b1 - h.b2 : 0.f; A.b1[i] = hit ? h.b1 : 0.f; A.b2[i] = hit ? h.b2 : 0.f;
 		if (A.px || A.nx || A.u) {
 			Surf sf = {};
 			V3 sn = {0, 0, 0};
-			if (hit) { hit_attributes(S, g, h, sf); sn = shading_normal(sf); }
+			if (hit) { hit_attributes(S, g, st.shade[h.surface], h.tri, h.b1, h.b2, sf); sn = shading_normal(sf); }
 			if (A.px) { A.px[i] = sf.pos.x; A.py[i] = sf.pos.y; A.pz[i] = sf.pos.z; }
 			if (A.nx) { A.nx[i] = sn.x; A.ny[i] = sn.y; A.nz[i] = sn.z; }
 			if (A.u) { A.u[i] = sf.u; A.v[i] = sf.v; }
@@ -559,16 +645,30 @@ static hipError_t set_lds(const void* fn, size_t bytes) {
 	return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+template <bool LDS, bool SUN, bool ALPHA>
+static hipError_t launch_pass_variant(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
+	if (LDS) {
+		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<LDS, SUN, ALPHA>), lds_bytes);
+		if (e != hipSuccess) return e;
+	}
+	hipLaunchKernelGGL((k_render_pass<LDS, SUN, ALPHA>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B);
+	return hipGetLastError();
+}
+
 hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, bool lds, size_t lds_bytes, int grid,
                               hipStream_t stream) {
-	if (lds) {
-		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<true>), lds_bytes);
-		if (e != hipSuccess) return e;
-		hipLaunchKernelGGL(k_render_pass<true>, dim3(grid), dim3(kBlock), lds_bytes, stream, S, P, B);
-	} else {
-		hipLaunchKernelGGL(k_render_pass<false>, dim3(grid), dim3(kBlock), 0, stream, S, P, B);
+	const bool sun = S.sun.present != 0, alpha = S.any_alpha != 0;
+	const int v = (lds ? 4 : 0) | (sun ? 2 : 0) | (alpha ? 1 : 0);
+	switch (v) {
+	case 0: return launch_pass_variant<false, false, false>(S, P, B, lds_bytes, grid, stream);
+	case 1: return launch_pass_variant<false, false, true>(S, P, B, lds_bytes, grid, stream);
+	case 2: return launch_pass_variant<false, true, false>(S, P, B, lds_bytes, grid, stream);
+	case 3: return launch_pass_variant<false, true, true>(S, P, B, lds_bytes, grid, stream);
+	case 4: return launch_pass_variant<true, false, false>(S, P, B, lds_bytes, grid, stream);
+	case 5: return launch_pass_variant<true, false, true>(S, P, B, lds_bytes, grid, stream);
+	case 6: return launch_pass_variant<true, true, false>(S, P, B, lds_bytes, grid, stream);
+	default: return launch_pass_variant<true, true, true>(S, P, B, lds_bytes, grid, stream);
 	}
-	return hipGetLastError();
 }
 hipError_t launch_resolve(const float4* sample_rad, float4* accum, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream) {
 	hipLaunchKernelGGL(k_resolve, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, sample_rad, accum, n_pixels, pass_spp);

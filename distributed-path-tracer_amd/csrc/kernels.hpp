@@ -7,8 +7,13 @@
 
 namespace ptx {
 
-constexpr int kBlock = 1024;      // threads per workgroup: 16 waves = 4 per SIMD, one workgroup per CU
+#ifndef PTX_BLOCK
+#define PTX_BLOCK 1024
+#endif
+constexpr int kBlock = PTX_BLOCK;  // threads per workgroup (one workgroup per CU): 1024 = 16 waves = 4 per SIMD
 constexpr uint32_t kChunk = 1024; // camera paths a wave takes per counter fetch (16 wave-iterations)
+// wave-private stream space, in float4: two ray buffers of 4 arrays + one hit-record array
+constexpr uint32_t kQueueFloat4PerWave = (2u * 4u + 1u) * kChunk;
 
 // Device view of a FlatScene (all pointers are device pointers).
 struct DevScene {
@@ -19,8 +24,10 @@ struct DevScene {
 	const uint32_t* refs;
 	const float4* tris;   // 3 per triangle
 	const float4* vattr;  // 2 per vertex
+	const ShadeRec* shade; // 1 per surface
 	int32_t n_models;
-	uint32_t n_nodes, n_refs, n_tris;
+	uint32_t n_surfaces, n_nodes, n_refs, n_tris;
+	uint32_t any_alpha;
 	CameraRec cam;
 	SunRec sun;
 };
@@ -38,7 +45,7 @@ struct RenderParams {
 };
 
 struct PassBuffers {
-	float4* queues;                   // [n_wave_slots][2][4][kChunk]
+	float4* queues;                   // [n_wave_slots][kQueueFloat4PerWave]
 	float4* sample_rad;               // [pass_spp][n_pixels]
 	uint32_t* chunk_counter;          // zeroed before each pass
 	unsigned long long* ray_counter;  // accumulates

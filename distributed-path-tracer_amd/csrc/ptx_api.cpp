@@ -5,6 +5,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -62,7 +63,7 @@ struct ptx_ctx {
 struct ptx_scene {
 	ptx_ctx* ctx = nullptr;
 	FlatScene host;
-	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr;
+	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr, d_shade;
 	DevScene dev{};
 	bool lds = false;
 	size_t lds_bytes = 0;
@@ -90,6 +91,7 @@ int upload_scene(ptx_scene* sc) {
 	HIP_TRY(up(sc->d_refs, h.kd_refs.data(), h.kd_refs.size() * 4, pad16(h.kd_refs.size() * 4)));
 	HIP_TRY(up(sc->d_tris, h.tris.data(), h.tris.size() * 48, h.tris.size() * 48));
 	HIP_TRY(up(sc->d_vattr, h.vattr.data(), h.vattr.size() * 32, h.vattr.size() * 32));
+	HIP_TRY(up(sc->d_shade, h.shade.data(), h.shade.size() * sizeof(ShadeRec), h.shade.size() * sizeof(ShadeRec)));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	DevScene& d = sc->dev;
 	d.models = (const ModelRec*)sc->d_models.p;
@@ -99,13 +101,16 @@ int upload_scene(ptx_scene* sc) {
 	d.refs = (const uint32_t*)sc->d_refs.p;
 	d.tris = (const float4*)sc->d_tris.p;
 	d.vattr = (const float4*)sc->d_vattr.p;
+	d.shade = (const ShadeRec*)sc->d_shade.p;
+	d.n_surfaces = (uint32_t)h.surfaces.size();
+	d.any_alpha = h.any_alpha ? 1u : 0u;
 	d.n_models = (int32_t)h.models.size();
 	d.n_nodes = (uint32_t)h.kd_nodes.size();
 	d.n_refs = (uint32_t)h.kd_refs.size();
 	d.n_tris = (uint32_t)h.tris.size();
 	d.cam = h.camera;
 	d.sun = h.sun;
-	sc->lds_bytes = h.tris.size() * 48 + pad16(h.kd_nodes.size() * 8) + pad16(h.kd_refs.size() * 4);
+	sc->lds_bytes = h.tris.size() * 48 + h.shade.size() * sizeof(ShadeRec) + pad16(h.kd_nodes.size() * 8) + pad16(h.kd_refs.size() * 4);
 	sc->lds = sc->lds_bytes <= kLdsBudget;
 	return PTX_OK;
 }
@@ -117,7 +122,7 @@ int finish_scene(ptx_ctx* ctx, ptx_scene* sc, ptx_scene** out) {
 		int rc = upload_scene(sc);
 		if (rc != PTX_OK) { delete sc; return rc; }
 	} else {
-		sc->lds_bytes = sc->host.tris.size() * 48 + pad16(sc->host.kd_nodes.size() * 8) + pad16(sc->host.kd_refs.size() * 4);
+		sc->lds_bytes = sc->host.tris.size() * 48 + sc->host.shade.size() * sizeof(ShadeRec) + pad16(sc->host.kd_nodes.size() * 8) + pad16(sc->host.kd_refs.size() * 4);
 		sc->lds = sc->lds_bytes <= kLdsBudget;
 	}
 	*out = sc;
@@ -237,7 +242,7 @@ void ptx_scene_destroy(ptx_scene* sc) {
 		(void)hipSetDevice(sc->ctx->device);
 		(void)hipStreamSynchronize(sc->ctx->stream);
 		sc->d_models.release(); sc->d_surfaces.release(); sc->d_materials.release(); sc->d_nodes.release();
-		sc->d_refs.release(); sc->d_tris.release(); sc->d_vattr.release();
+		sc->d_refs.release(); sc->d_tris.release(); sc->d_vattr.release(); sc->d_shade.release();
 	}
 	delete sc;
 }
@@ -328,7 +333,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 
 	const int grid = c->n_cu;
 	const size_t n_slots = (size_t)grid * (kBlock / 64);
-	HIP_TRY(c->queues.ensure(n_slots * 2 * 4 * kChunk * sizeof(float4)));
+	HIP_TRY(c->queues.ensure(n_slots * (size_t)kQueueFloat4PerWave * sizeof(float4)));
 	HIP_TRY(c->sample_rad.ensure((size_t)pass_spp * n_pixels * sizeof(float4)));
 	HIP_TRY(c->counters.ensure(64));
 	uint32_t* chunk_counter = (uint32_t*)c->counters.p;
@@ -373,6 +378,11 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 		unsigned long long rays = 0;
 		HIP_TRY(hipMemcpy(&rays, ray_counter, 8, hipMemcpyDeviceToHost));
 		stats->rays = rays;
+#ifdef PTX_STAMP
+		unsigned long long ph[2] = {0, 0};
+		HIP_TRY(hipMemcpy(ph, ray_counter + 1, 16, hipMemcpyDeviceToHost));
+		fprintf(stderr, "[PTX_STAMP] wave-cycles extend=%llu shade=%llu  (extend share %.1f%%)\n", ph[0], ph[1], 100.0 * ph[0] / (double)(ph[0] + ph[1]));
+#endif
 		stats->samples = (uint64_t)cfg->spp * n_pixels;
 		stats->passes = n_pass;
 		double ms = 0;

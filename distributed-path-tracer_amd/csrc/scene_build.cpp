@@ -155,6 +155,7 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 	s.kd_nodes.clear(); s.kd_refs.clear(); s.tris.clear(); s.vattr.clear();
 	s.kd_max_depth = 0;
 	s.any_texture = false;
+	s.any_alpha = false;
 
 	// vertex attribute records (global vertex ids)
 	const size_t nv = s.vertices.size() / 11;
@@ -227,6 +228,8 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 		if (s.material_tex.size() >= 7 * (si + 1))
 			for (int k = 0; k < 7; k++) if (s.material_tex[7 * si + k]) mr.tex_mask |= 1u << k;
 		if (mr.tex_mask) s.any_texture = true;
+		// math::is_approx(opacity, 1) (renderer.cpp:466) false, or a shadow catcher => pass-through code is needed
+		if (!(mr.opacity == 1.0f || std::fabs(mr.opacity - 1.0f) < kEps) || mr.shadow_catcher) s.any_alpha = true;
 	}
 
 	for (size_t mi = 0; mi < n_models; mi++) {
@@ -251,6 +254,15 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 		memcpy(mr.bmin, b.lo, 12);
 		memcpy(mr.bmax, b.hi, 12);
 	}
+	s.shade.assign(n_surf, ShadeRec{});
+	for (size_t mi = 0; mi < n_models; mi++)
+		for (int32_t k = 0; k < s.models[mi].n_surfaces; k++) {
+			ShadeRec& r = s.shade[s.models[mi].first_surface + k];
+			memcpy(r.basis, s.models[mi].basis, 36);
+			memcpy(r.origin, s.models[mi].origin, 12);
+			memcpy(r.nmat, s.models[mi].nmat, 36);
+			r.mat = s.materials[s.models[mi].first_surface + k];
+		}
 
 	memcpy(s.camera.origin, cam, 12);
 	memcpy(s.camera.basis, cam + 3, 36);
