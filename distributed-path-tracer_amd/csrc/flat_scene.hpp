@@ -72,6 +72,21 @@ struct ShadeRec {
 };
 static_assert(sizeof(ShadeRec) == 144, "ShadeRec layout");
 
+// ---- ray space: a distinct world->local transform. Models whose entity transforms are bitwise equal
+// share one, so the local ray (origin, normalised direction, reciprocal direction) is computed once per
+// space instead of once per model (model.cpp:22-29 recomputes it per model; same operations, same bits).
+struct SpaceRec {
+	float inv_basis[9];
+	float inv_origin[3];
+};
+
+// ---- visit list: one entry per surface in the order renderer::intersect would reach it
+// (models in visit order, surfaces in model order). 32 B = 2 x float4.
+struct VisitRec {
+	float bmin[3]; uint32_t kd_root;
+	float bmax[3]; uint32_t model_space;  // model index | space index << 24
+};
+
 struct CameraRec { float origin[3]; float basis[9]; float fov; float tan_half_fov; };
 struct SunRec { float basis[9]; float energy[3]; float angular_radius; uint32_t present; };
 
@@ -91,6 +106,9 @@ struct FlatScene {
 	std::vector<SurfaceRec> surfaces;
 	std::vector<MaterialRec> materials;
 	std::vector<ShadeRec> shade;         // per surface
+	std::vector<SpaceRec> spaces;        // distinct world->local transforms
+	std::vector<uint32_t> model_space;   // per model
+	std::vector<VisitRec> visits;        // per surface
 	std::vector<KdNode> kd_nodes;
 	std::vector<uint32_t> kd_refs;       // global triangle ids
 	std::vector<TriRec> tris;

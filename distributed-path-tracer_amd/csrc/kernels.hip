@@ -16,6 +16,8 @@
 // function cites what it restates (paths relative to path-tracer-core/path_tracer_lib/path_tracer/).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <stdio.h>
 
 #include "kernels.hpp"
 
@@ -97,8 +99,16 @@ DEV float tri_test(V3 a, V3 b, V3 c, V3 o, V3 d, float& alpha, float& beta, floa
 struct MeshHit { float t; float b1, b2; uint32_t tri; };
 
 constexpr int kRegStack = 3;    // pending KD subtrees kept in registers (covers > 99 % of traversals)
-constexpr int kSpillStack = 24; // deeper entries go to a private array: the reference pushes at most one entry per
-                                // level and its trees are at most 26 levels deep (mesh.hpp:34, max_depth = 25)
+constexpr int kSpillStack = 24; // deeper entries go to a per-lane overflow area in global memory (touched by < 1 % of
+                                // traversals): the reference pushes at most one entry per level and its trees are at
+                                // most 26 levels deep (mesh.hpp:34, max_depth = 25)
+
+// Overflow stack of one lane: entry k lives at base[k * 64] (uint2 = node, min_dist bits), so that the 64 lanes of a wave
+// touch one 512-byte row per level. An explicit global array, not a private one: a private array would be turned into
+// registers + compare/select chains, or into scratch whose address arithmetic sits in every push and pop.
+struct Spill { uint2* base; };
+DEV void spill_put(const Spill& sp, int k, uint32_t node, float m) { sp.base[k * 64] = make_uint2(node, __float_as_uint(m)); }
+DEV void spill_get(const Spill& sp, int k, uint32_t& node, float& m) { uint2 v = sp.base[k * 64]; node = v.x; m = __uint_as_float(v.y); }
 
 // geometry::aabb::intersect with the reciprocal direction hoisted: the same local ray is tested against the
 // model box and every surface box, and 1/dir has one value per ray whatever box it meets.
@@ -117,7 +127,7 @@ DEV bool aabb_test_inv(const float* mn, const float* mx, V3 o, V3 inv, float& nr
 // Stack entries are (node, min_dist) only: the max_dist the reference stores with an entry is always the
 // min_dist of the entry beneath it (each push hands its old max_dist to the pushed subtree and continues
 // with max_dist = split_dist = the pushed min_dist), and the AABB exit distance for the bottom one.
-DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, MeshHit& out, uint32_t* spill_node, float* spill_min) {
+DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, MeshHit& out, const Spill& spill) {
 	float nr, fr;
 	if (!aabb_test_inv(sf.bmin, sf.bmax, o, inv, nr, fr)) return false;
 	int sp = 0;
@@ -132,7 +142,7 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, 
 			sp--;
 			node = n0; min_dist = m0;
 			n0 = n1; m0 = m1; n1 = n2; m1 = m2;
-			if (sp >= kRegStack) { n2 = spill_node[sp - kRegStack]; m2 = spill_min[sp - kRegStack]; }
+			if (sp >= kRegStack) spill_get(spill, sp - kRegStack, n2, m2);
 			max_dist = sp > 0 ? m0 : fr;
 		}
 		have = false;
@@ -154,7 +164,7 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, 
 			else if (split_dist < min_dist) { next = second; has_next = has_second; }
 			else {
 				if (has_second && sp < kRegStack + kSpillStack) {
-					if (sp >= kRegStack) { spill_node[sp - kRegStack] = n2; spill_min[sp - kRegStack] = m2; }
+					if (sp >= kRegStack) spill_put(spill, sp - kRegStack, n2, m2);
 					n2 = n1; m2 = m1; n1 = n0; m1 = m0; n0 = second; m0 = split_dist;
 					sp++;
 				}
@@ -188,7 +198,7 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, 
 struct SceneHit { float dist; int surface; uint32_t tri; float b1, b2; };
 
 // renderer::intersect (core/renderer.cpp:645-671) over scene::model::intersect (scene/model.cpp:20-72)
-DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& best, uint32_t* spill_node, float* spill_min) {
+DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& best, const Spill& spill) {
 	best.dist = -1.0f;
 	best.surface = -1;
 	for (int m = 0; m < S.n_models; m++) {
@@ -204,7 +214,7 @@ DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& 
 		int hit_surface = -1;
 		for (int s = 0; s < M.n_surfaces; s++) {
 			MeshHit h;
-			if (!mesh_traverse(g, S.surfaces[M.first_surface + s], lo, ld, inv, h, spill_node, spill_min)) continue;
+			if (!mesh_traverse(g, S.surfaces[M.first_surface + s], lo, ld, inv, h, spill)) continue;
 			if (h.t < nearest.t || !(nearest.t >= 0)) { nearest = h; hit_surface = M.first_surface + s; }
 		}
 		if (!(nearest.t >= 0)) continue;
@@ -216,6 +226,173 @@ DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& 
 		}
 	}
 	return best.surface >= 0;
+}
+
+// ------------------------------------------------------------------------------------ wave-cooperative closest hit
+// Same arithmetic and the same visiting order PER RAY as scene_traverse above, but scheduled for a
+// 64-lane wave: every lane walks its own ray through its own sequence of (surface, KD node, leaf triangle)
+// steps, and each trip of the loop runs ONE of two code sections for the whole wave —
+//   TRI     : one triangle test for every lane that has a leaf triangle pending  (the bulk of the work)
+//   ADVANCE : one bookkeeping step (finish leaf / pop / next surface / KD branch step) for the others
+// — whichever has more lanes waiting. Lanes are therefore never held up by a model or a subtree they do
+// not touch (the per-model loop costs the sum over models of the slowest lane), and each section runs with
+// at least half of the unfinished lanes.
+// Setup is wave-uniform: the local ray of every ray space (SpaceRec) and one AABB test per model / surface
+// give each lane a bit mask of the surfaces it has to traverse.
+// Must be called from wave-uniform control flow; `active` masks lanes without a ray.
+#ifdef PTX_STAMP
+__device__ unsigned long long g_diag[8];
+#endif
+constexpr uint32_t ST_NEXT = 0, ST_NODE = 1, ST_LEAF = 2, ST_POP = 3, ST_DONE = 4;
+constexpr int kMaxFastSurfaces = 64, kMaxFastSpaces = 2;
+
+template <int NSPACE>
+DEV void extend64(const DevScene& S, const Geom& g, const ShadeRec* shade, const VisitRec* visits, V3 o, V3 d, bool active,
+                  SceneHit& best, const Spill& spill) {
+	// ---- uniform setup: local rays, surface mask
+	V3 lo[NSPACE], ld[NSPACE], inv[NSPACE];
+#pragma unroll
+	for (int k = 0; k < NSPACE; k++) {
+		const SpaceRec& sp = S.spaces[k];
+		lo[k] = mulmv(sp.inv_basis, o) + mk(sp.inv_origin[0], sp.inv_origin[1], sp.inv_origin[2]);
+		ld[k] = normalize(mulmv(sp.inv_basis, d));
+		inv[k] = mk(1.0f / ld[k].x, 1.0f / ld[k].y, 1.0f / ld[k].z);
+	}
+	uint64_t mask = 0;
+	for (int m = 0; m < S.n_models; m++) {
+		const ModelRec& M = S.models[m];
+		const bool s1 = NSPACE > 1 && S.model_space[m] != 0;  // wave-uniform
+		const V3 mo = s1 ? lo[NSPACE - 1] : lo[0], mi = s1 ? inv[NSPACE - 1] : inv[0];
+		float nr, fr;
+		const bool mh = aabb_test_inv(M.bmin, M.bmax, mo, mi, nr, fr);
+		for (int k = 0; k < M.n_surfaces; k++) {
+			const SurfaceRec& sf = S.surfaces[M.first_surface + k];
+			const bool sh = mh && aabb_test_inv(sf.bmin, sf.bmax, mo, mi, nr, fr);
+			mask |= sh ? (1ull << (M.first_surface + k)) : 0ull;
+		}
+	}
+	if (!active) mask = 0;
+
+	// ---- per-lane traversal state
+	best.dist = -1.0f; best.surface = -1; best.tri = 0; best.b1 = 0; best.b2 = 0;
+	uint32_t st = ST_NEXT;
+	int cur_model = -1, cur_surf = -1;
+	V3 co = lo[0], cd = ld[0];                      // local ray of the surface being traversed
+	float nt = -1.0f, nb1 = 0, nb2 = 0; uint32_t ntri = 0; int nsurf = -1;   // nearest within the current model (local t)
+	uint32_t node = 0; float tmin = 0, tmax = 0, tfar = 0; int sp = 0;
+	uint32_t n0 = 0, n1 = 0, n2 = 0; float m0 = 0, m1 = 0, m2 = 0;
+	uint32_t rcur = 0, rend = 0; float lt = -1.0f, lb1 = 0, lb2 = 0; uint32_t ltri = 0;
+
+#ifdef PTX_STAMP
+	uint32_t dg_tri_trips = 0, dg_adv_trips = 0, dg_tri_lanes = 0, dg_adv_lanes = 0;
+#endif
+	for (;;) {
+		const bool want_tri = rcur < rend;
+		const bool want_adv = !want_tri && st != ST_DONE;
+		const uint64_t mt = __ballot(want_tri), ma = __ballot(want_adv);
+		if ((mt | ma) == 0) break;
+#ifdef PTX_STAMP
+		if (__popcll(mt) >= __popcll(ma)) { dg_tri_trips++; dg_tri_lanes += __popcll(mt); } else { dg_adv_trips++; dg_adv_lanes += __popcll(ma); }
+#endif
+		if (__popcll(mt) >= __popcll(ma)) {
+			// ---------------- TRI: one leaf triangle (mesh.cpp:381-389; ties keep the first)
+			if (want_tri) {
+				const uint32_t ti = g.refs[rcur];
+				const float4 A = g.tris[3 * ti], B = g.tris[3 * ti + 1], C = g.tris[3 * ti + 2];
+				float al, be, ga;
+				const float t = tri_test(mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), mk(C.x, C.y, C.z), co, cd, al, be, ga);
+				if (t >= 0 && t <= tmax && (t < lt || !(lt >= 0))) { lt = t; lb1 = be; lb2 = ga; ltri = ti; }
+				rcur++;
+			}
+		} else if (want_adv) {
+			// ---------------- ADVANCE
+			if (st == ST_LEAF) {
+				if (lt >= 0) {   // the leaf produced a hit: mesh::intersect returns it (mesh.cpp:397-401)
+					if (lt < nt || !(nt >= 0)) { nt = lt; nb1 = lb1; nb2 = lb2; ntri = ltri; nsurf = cur_surf; }   // model.cpp:45-49
+					st = ST_NEXT;
+				} else st = ST_POP;
+			}
+			if (st == ST_POP) {
+				if (sp == 0) st = ST_NEXT;
+				else {
+					sp--;
+					node = n0; tmin = m0;
+					n0 = n1; m0 = m1; n1 = n2; m1 = m2;
+					if (sp >= kRegStack) spill_get(spill, sp - kRegStack, n2, m2);
+					tmax = sp > 0 ? m0 : tfar;
+					st = ST_NODE;
+				}
+			}
+			if (st == ST_NEXT) {
+				const bool more = mask != 0;
+				const int s = more ? (int)__builtin_ctzll(mask) : 0;
+				uint32_t ms = 0; float4 v0 = make_float4(0, 0, 0, 0), v1 = v0;
+				if (more) { v0 = reinterpret_cast<const float4*>(visits)[2 * s]; v1 = reinterpret_cast<const float4*>(visits)[2 * s + 1]; ms = __float_as_uint(v1.w); }
+				const int model = more ? (int)(ms & 0xFFFFFFu) : -2;
+				if (model != cur_model) {
+					if (nt >= 0) {   // close the model: local -> world distance (model.cpp:62-63), then renderer.cpp:663-669
+						const ShadeRec& R = shade[nsurf];
+						const float wd = length(mulmv(R.basis, cd * nt));
+						if (wd >= 0 && (wd < best.dist || !(best.dist >= 0))) { best.dist = wd; best.surface = nsurf; best.tri = ntri; best.b1 = nb1; best.b2 = nb2; }
+					}
+					nt = -1.0f;
+					cur_model = model;
+				}
+				if (!more) st = ST_DONE;
+				else {
+					mask &= mask - 1;
+					cur_surf = s;
+					const bool s1 = NSPACE > 1 && (ms >> 24) != 0;
+					co = s1 ? lo[NSPACE - 1] : lo[0];
+					cd = s1 ? ld[NSPACE - 1] : ld[0];
+					const V3 ci = s1 ? inv[NSPACE - 1] : inv[0];
+					const float bmn[3] = {v0.x, v0.y, v0.z}, bmx[3] = {v1.x, v1.y, v1.z};
+					float nr, fr;
+					aabb_test_inv(bmn, bmx, co, ci, nr, fr);   // hit is known from the mask; the distances are needed
+					node = __float_as_uint(v0.w); tmin = nr; tmax = fr; tfar = fr; sp = 0;
+					st = ST_NODE;
+				}
+			}
+			if (st == ST_NODE) {
+				const uint2 nd = g.nodes[node];
+				if ((nd.y & 3u) == KD_LEAF) {
+					rcur = nd.x; rend = nd.x + (nd.y >> 2);
+					lt = -1.0f;
+					st = ST_LEAF;
+				} else {   // one branch step (mesh.cpp:333-369)
+					const uint32_t axis = nd.y & 3u;
+					const float split = __uint_as_float(nd.x);
+					const float oa = sel3(co, axis), da = sel3(cd, axis);
+					const float split_dist = (split - oa) / da;
+					const bool has_l = nd.y & 4u, has_r = nd.y & 8u;
+					const uint32_t li = nd.y >> 4, ri = li + (has_l ? 1u : 0u);
+					const bool left_first = oa < split;
+					const uint32_t first = left_first ? li : ri, second = left_first ? ri : li;
+					const bool has_first = left_first ? has_l : has_r, has_second = left_first ? has_r : has_l;
+					bool has_next;
+					if (split_dist < 0 || split_dist > tmax) { node = first; has_next = has_first; }
+					else if (split_dist < tmin) { node = second; has_next = has_second; }
+					else {
+						if (has_second && sp < kRegStack + kSpillStack) {
+							if (sp >= kRegStack) spill_put(spill, sp - kRegStack, n2, m2);
+							n2 = n1; m2 = m1; n1 = n0; m1 = m0; n0 = second; m0 = split_dist;
+							sp++;
+						}
+						node = first; has_next = has_first;
+						tmax = split_dist;
+					}
+					if (!has_next) st = ST_POP;
+				}
+			}
+		}
+	}
+#ifdef PTX_STAMP
+	if ((threadIdx.x & 63u) == 0) {
+		atomicAdd(g_diag + 0, (unsigned long long)dg_tri_trips); atomicAdd(g_diag + 1, (unsigned long long)dg_adv_trips);
+		atomicAdd(g_diag + 2, (unsigned long long)dg_tri_lanes); atomicAdd(g_diag + 3, (unsigned long long)dg_adv_lanes);
+		atomicAdd(g_diag + 4, 1ull);
+	}
+#endif
 }
 
 struct Surf { V3 pos, nrm, tan; float u, v; };
@@ -354,7 +531,7 @@ DEV void camera_ray(const DevScene& S, const RenderParams& P, uint32_t x, uint32
 // (sun shadow rays; opacity / shadow-catcher pass-through): scenes without them get a kernel without it.
 template <bool SUN, bool ALPHA>
 DEV bool shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, const RenderParams& P, uint32_t pixel, uint32_t sample,
-                      uint32_t depth, SceneHit h, V3& o, V3& d, V3& T, V3& L, uint32_t& rays, uint32_t* spill_node, float* spill_min) {
+                      uint32_t depth, SceneHit h, V3& o, V3& d, V3& T, V3& L, uint32_t& rays, const Spill& spill) {
 	uint32_t pass = 0;
 	for (;;) {
 		if (h.surface < 0) {
@@ -393,7 +570,7 @@ DEV bool shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, c
 					V3 so = sf.pos + din * kEps, sd = normalize(din);
 					SceneHit sh;
 					rays++;
-					bool shadowed = scene_traverse(S, g, so, sd, sh, spill_node, spill_min);
+					bool shadowed = scene_traverse(S, g, so, sd, sh, spill);
 					bool catcher = ALPHA && mt.shadow_catcher && depth == 0;
 					if (!shadowed) {
 						if (catcher) pass_through = true;                    // lit shadow catcher behaves as fully transparent
@@ -416,7 +593,7 @@ DEV bool shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, c
 				pass++;
 				if (pass > 4096) return false;  // safety bound; the reference would recurse without limit
 				rays++;
-				scene_traverse(S, g, o, d, h, spill_node, spill_min);
+				scene_traverse(S, g, o, d, h, spill);
 				continue;
 			}
 		}
@@ -435,29 +612,32 @@ DEV bool shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, c
 }
 
 // ------------------------------------------------------------------------------------ LDS staging
-struct Staged { Geom g; const ShadeRec* shade; };
+struct Staged { Geom g; const ShadeRec* shade; const VisitRec* visits; };
 
 template <bool LDS>
 DEV Staged stage_geometry(const DevScene& S, unsigned char* smem) {
-	if constexpr (!LDS) return {{S.nodes, S.refs, S.tris}, S.shade};
+	if constexpr (!LDS) return {{S.nodes, S.refs, S.tris}, S.shade, S.visits};
 	else {
-		// [triangle records][shade records][KD nodes][leaf refs], each region a multiple of 16 B
+		// [triangle records][shade records][visit records][KD nodes][leaf refs], each region a multiple of 16 B
 		uint4* dst = reinterpret_cast<uint4*>(smem);
-		const uint32_t n_tri16 = S.n_tris * 3, n_shade16 = S.n_surfaces * 9, n_node16 = (S.n_nodes + 1) / 2, n_ref16 = (S.n_refs + 3) / 4;
+		const uint32_t n_tri16 = S.n_tris * 3, n_shade16 = S.n_surfaces * 9, n_visit16 = S.n_surfaces * 2, n_node16 = (S.n_nodes + 1) / 2, n_ref16 = (S.n_refs + 3) / 4;
 		const uint4* src_t = reinterpret_cast<const uint4*>(S.tris);
 		const uint4* src_s = reinterpret_cast<const uint4*>(S.shade);
+		const uint4* src_v = reinterpret_cast<const uint4*>(S.visits);
 		const uint4* src_n = reinterpret_cast<const uint4*>(S.nodes);
 		const uint4* src_r = reinterpret_cast<const uint4*>(S.refs);
 		uint4* d_s = dst + n_tri16;
-		uint4* d_n = d_s + n_shade16;
+		uint4* d_v = d_s + n_shade16;
+		uint4* d_n = d_v + n_visit16;
 		uint4* d_r = d_n + n_node16;
 		for (uint32_t i = threadIdx.x; i < n_tri16; i += blockDim.x) dst[i] = src_t[i];
 		for (uint32_t i = threadIdx.x; i < n_shade16; i += blockDim.x) d_s[i] = src_s[i];
+		for (uint32_t i = threadIdx.x; i < n_visit16; i += blockDim.x) d_v[i] = src_v[i];
 		for (uint32_t i = threadIdx.x; i < n_node16; i += blockDim.x) d_n[i] = src_n[i];
 		for (uint32_t i = threadIdx.x; i < n_ref16; i += blockDim.x) d_r[i] = src_r[i];
 		__syncthreads();
 		return {{reinterpret_cast<const uint2*>(d_n), reinterpret_cast<const uint32_t*>(d_r), reinterpret_cast<const float4*>(dst)},
-		        reinterpret_cast<const ShadeRec*>(d_s)};
+		        reinterpret_cast<const ShadeRec*>(d_s), reinterpret_cast<const VisitRec*>(d_v)};
 	}
 }
 
@@ -468,7 +648,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 // Per wave and chunk of kChunk paths, every bounce is two sweeps over the wave's private ray stream:
 //   EXTEND: (generate or) load ray -> closest hit -> 16-byte hit record        (traversal state only in registers)
 //   SHADE : load ray + hit + path state -> BSDF, radiance, next ray -> compacted write (path state only)
-template <bool LDS, bool SUN, bool ALPHA>
+template <bool LDS, bool SUN, bool ALPHA, int NSPACE>
 __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S, RenderParams P, PassBuffers B) {
 	const Staged st = stage_geometry<LDS>(S, g_smem);
 	const Geom g = st.g;
@@ -477,8 +657,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S, RenderParams
 	// wave-private streams: 2 ray buffers x 4 float4 arrays x kChunk entries, then 1 hit array
 	float4* qbase = B.queues + (size_t)wave_slot * (kQueueFloat4PerWave);
 	float4* hbuf = qbase + 2u * 4u * kChunk;
-	uint32_t spill_node[kSpillStack];
-	float spill_min[kSpillStack];
+	const Spill spill{B.spill + (size_t)wave_slot * (kSpillStack * 64) + lane};
 	uint32_t rays = 0;
 
 	for (;;) {
@@ -500,8 +679,9 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S, RenderParams
 			// ---------------- EXTEND
 			for (uint32_t base = 0; base < n_in; base += 64) {
 				const uint32_t i = base + lane;
-				if (i < n_in) {
-					V3 o, d;
+				const bool active = i < n_in;
+				V3 o = {0, 0, 0}, d = {0, 0, 1};
+				if (active) {
 					if (depth == 0) {
 						const uint32_t id = (uint32_t)first + i;  // id within the pass: sample-major, pixel-minor
 						const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
@@ -514,10 +694,11 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S, RenderParams
 						o = mk(q0.x, q0.y, q0.z);
 						d = mk(q1.x, q1.y, q1.z);
 					}
-					SceneHit h;
-					scene_traverse(S, g, o, d, h, spill_node, spill_min);
-					hbuf[i] = make_float4(__int_as_float(h.surface), __uint_as_float(h.tri), h.b1, h.b2);
 				}
+				SceneHit h;
+				if constexpr (NSPACE > 0) extend64<NSPACE>(S, g, st.shade, st.visits, o, d, active, h, spill);
+				else if (active) scene_traverse(S, g, o, d, h, spill);
+				if (active) hbuf[i] = make_float4(__int_as_float(h.surface), __uint_as_float(h.tri), h.b1, h.b2);
 			}
 			rays += n_in > lane ? (n_in - lane + 63u) / 64u : 0u;  // rays this lane traced in the sweep
 			// the wave re-reads below what other lanes of this wave just wrote
@@ -549,7 +730,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S, RenderParams
 					const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
 					const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
 					alive = shade_vertex<SUN, ALPHA>(S, g, st.shade, P, py * P.W + px, P.sample0 + s_local, depth, h, o, d, T, L, rays,
-					                                 spill_node, spill_min);
+					                                 spill);
 					if (last) alive = false;  // trace(0, ..) returns black: renderer.cpp:438-439
 					if (!alive) B.sample_rad[id] = make_float4(L.x, L.y, L.z, 1.0f);
 				}
@@ -590,16 +771,22 @@ __global__ void k_resolve(const float4* __restrict__ sample_rad, float4* __restr
 }
 
 // ------------------------------------------------------------------------------------ batch intersect
-template <bool LDS>
+template <bool LDS, int NSPACE>
 __global__ void __launch_bounds__(kBlock) k_intersect_batch(DevScene S, IntersectArgs A) {
 	const Staged st = stage_geometry<LDS>(S, g_smem);
 	const Geom g = st.g;
-	uint32_t spill_node[kSpillStack];
-	float spill_min[kSpillStack];
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (size_t)gridDim.x * blockDim.x) {
-		V3 o = mk(A.ox[i], A.oy[i], A.oz[i]), d = mk(A.dx[i], A.dy[i], A.dz[i]);
+	const Spill spill{A.spill + (size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * (kSpillStack * 64) + (threadIdx.x & 63u)};
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	const size_t n_round = (A.n + stride - 1) / stride * stride;   // every wave makes the same number of trips (extend64 is wave-cooperative)
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+		const bool active = i < A.n;
+		V3 o = {0, 0, 0}, d = {0, 0, 1};
+		if (active) { o = mk(A.ox[i], A.oy[i], A.oz[i]); d = mk(A.dx[i], A.dy[i], A.dz[i]); }
 		SceneHit h;
-		bool hit = scene_traverse(S, g, o, d, h, spill_node, spill_min);
+		if constexpr (NSPACE > 0) extend64<NSPACE>(S, g, st.shade, st.visits, o, d, active, h, spill);
+		else if (active) scene_traverse(S, g, o, d, h, spill);
+		if (!active) continue;
+		const bool hit = h.surface >= 0;
 		A.distance[i] = hit ? h.dist : -1.0f;
 		A.surface[i] = hit ? h.surface : -1;
 		A.triangle[i] = hit ? (int32_t)(h.tri - S.surfaces[h.surface].tri_base) : -1;
@@ -645,14 +832,23 @@ static hipError_t set_lds(const void* fn, size_t bytes) {
 	return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <bool LDS, bool SUN, bool ALPHA>
+template <bool LDS, bool SUN, bool ALPHA, int NSPACE>
 static hipError_t launch_pass_variant(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
 	if (LDS) {
-		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<LDS, SUN, ALPHA>), lds_bytes);
+		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<LDS, SUN, ALPHA, NSPACE>), lds_bytes);
 		if (e != hipSuccess) return e;
 	}
-	hipLaunchKernelGGL((k_render_pass<LDS, SUN, ALPHA>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B);
+	hipLaunchKernelGGL((k_render_pass<LDS, SUN, ALPHA, NSPACE>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B);
 	return hipGetLastError();
+}
+template <bool LDS, bool SUN, bool ALPHA>
+static hipError_t launch_pass_space(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
+	// wave-cooperative traversal needs the surface mask in 64 bits and the local rays of all spaces in registers
+	static const bool force_simple = getenv("PTX_FORCE_SIMPLE") != nullptr;  // experiments: per-lane traversal everywhere
+	const bool fast = !force_simple && S.n_surfaces <= (uint32_t)kMaxFastSurfaces && S.n_spaces <= (uint32_t)kMaxFastSpaces;
+	if (fast && S.n_spaces <= 1) return launch_pass_variant<LDS, SUN, ALPHA, 1>(S, P, B, lds_bytes, grid, stream);
+	if (fast) return launch_pass_variant<LDS, SUN, ALPHA, 2>(S, P, B, lds_bytes, grid, stream);
+	return launch_pass_variant<LDS, SUN, ALPHA, 0>(S, P, B, lds_bytes, grid, stream);
 }
 
 hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, bool lds, size_t lds_bytes, int grid,
@@ -660,29 +856,48 @@ hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const Pa
 	const bool sun = S.sun.present != 0, alpha = S.any_alpha != 0;
 	const int v = (lds ? 4 : 0) | (sun ? 2 : 0) | (alpha ? 1 : 0);
 	switch (v) {
-	case 0: return launch_pass_variant<false, false, false>(S, P, B, lds_bytes, grid, stream);
-	case 1: return launch_pass_variant<false, false, true>(S, P, B, lds_bytes, grid, stream);
-	case 2: return launch_pass_variant<false, true, false>(S, P, B, lds_bytes, grid, stream);
-	case 3: return launch_pass_variant<false, true, true>(S, P, B, lds_bytes, grid, stream);
-	case 4: return launch_pass_variant<true, false, false>(S, P, B, lds_bytes, grid, stream);
-	case 5: return launch_pass_variant<true, false, true>(S, P, B, lds_bytes, grid, stream);
-	case 6: return launch_pass_variant<true, true, false>(S, P, B, lds_bytes, grid, stream);
-	default: return launch_pass_variant<true, true, true>(S, P, B, lds_bytes, grid, stream);
+	case 0: return launch_pass_space<false, false, false>(S, P, B, lds_bytes, grid, stream);
+	case 1: return launch_pass_space<false, false, true>(S, P, B, lds_bytes, grid, stream);
+	case 2: return launch_pass_space<false, true, false>(S, P, B, lds_bytes, grid, stream);
+	case 3: return launch_pass_space<false, true, true>(S, P, B, lds_bytes, grid, stream);
+	case 4: return launch_pass_space<true, false, false>(S, P, B, lds_bytes, grid, stream);
+	case 5: return launch_pass_space<true, false, true>(S, P, B, lds_bytes, grid, stream);
+	case 6: return launch_pass_space<true, true, false>(S, P, B, lds_bytes, grid, stream);
+	default: return launch_pass_space<true, true, true>(S, P, B, lds_bytes, grid, stream);
 	}
 }
+#ifdef PTX_STAMP
+void diag_dump() {
+	unsigned long long h[8];
+	if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof h) != hipSuccess) return;
+	fprintf(stderr, "[PTX_STAMP] extend64 calls=%llu  per call: tri trips %.2f (%.1f lanes), adv trips %.2f (%.1f lanes)\n", h[4],
+	        (double)h[0] / h[4], (double)h[2] / (h[0] ? h[0] : 1), (double)h[1] / h[4], (double)h[3] / (h[1] ? h[1] : 1));
+}
+#endif
 hipError_t launch_resolve(const float4* sample_rad, float4* accum, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream) {
 	hipLaunchKernelGGL(k_resolve, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, sample_rad, accum, n_pixels, pass_spp);
 	return hipGetLastError();
 }
-hipError_t launch_intersect(const DevScene& S, const IntersectArgs& A, bool lds, size_t lds_bytes, int grid, hipStream_t stream) {
-	if (lds) {
-		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_intersect_batch<true>), lds_bytes);
+template <bool LDS, int NSPACE>
+static hipError_t launch_intersect_variant(const DevScene& S, const IntersectArgs& A, size_t lds_bytes, int grid, hipStream_t stream) {
+	if (LDS) {
+		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_intersect_batch<LDS, NSPACE>), lds_bytes);
 		if (e != hipSuccess) return e;
-		hipLaunchKernelGGL(k_intersect_batch<true>, dim3(grid), dim3(kBlock), lds_bytes, stream, S, A);
-	} else {
-		hipLaunchKernelGGL(k_intersect_batch<false>, dim3(grid), dim3(kBlock), 0, stream, S, A);
 	}
+	hipLaunchKernelGGL((k_intersect_batch<LDS, NSPACE>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, A);
 	return hipGetLastError();
+}
+hipError_t launch_intersect(const DevScene& S, const IntersectArgs& A, bool lds, size_t lds_bytes, int grid, hipStream_t stream) {
+	const bool fast = S.n_surfaces <= (uint32_t)kMaxFastSurfaces && S.n_spaces <= (uint32_t)kMaxFastSpaces;
+	const int ns = !fast ? 0 : (S.n_spaces <= 1 ? 1 : 2);
+	if (lds) {
+		if (ns == 1) return launch_intersect_variant<true, 1>(S, A, lds_bytes, grid, stream);
+		if (ns == 2) return launch_intersect_variant<true, 2>(S, A, lds_bytes, grid, stream);
+		return launch_intersect_variant<true, 0>(S, A, lds_bytes, grid, stream);
+	}
+	if (ns == 1) return launch_intersect_variant<false, 1>(S, A, lds_bytes, grid, stream);
+	if (ns == 2) return launch_intersect_variant<false, 2>(S, A, lds_bytes, grid, stream);
+	return launch_intersect_variant<false, 0>(S, A, lds_bytes, grid, stream);
 }
 hipError_t launch_tonemap(const float4* accum, uint32_t n_pixels, float spp, uchar4* out, hipStream_t stream) {
 	hipLaunchKernelGGL(k_tonemap, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, accum, n_pixels, spp, out);

@@ -14,6 +14,7 @@ constexpr int kBlock = PTX_BLOCK;  // threads per workgroup (one workgroup per C
 constexpr uint32_t kChunk = 1024; // camera paths a wave takes per counter fetch (16 wave-iterations)
 // wave-private stream space, in float4: two ray buffers of 4 arrays + one hit-record array
 constexpr uint32_t kQueueFloat4PerWave = (2u * 4u + 1u) * kChunk;
+constexpr uint32_t kSpillWords = 24u * 64u;  // uint2 per wave: kSpillStack levels x 64 lanes
 
 // Device view of a FlatScene (all pointers are device pointers).
 struct DevScene {
@@ -25,9 +26,13 @@ struct DevScene {
 	const float4* tris;   // 3 per triangle
 	const float4* vattr;  // 2 per vertex
 	const ShadeRec* shade; // 1 per surface
+	const VisitRec* visits; // 1 per surface, visit order
+	const SpaceRec* spaces; // distinct world->local transforms
+	const uint32_t* model_space; // per model
 	int32_t n_models;
 	uint32_t n_surfaces, n_nodes, n_refs, n_tris;
 	uint32_t any_alpha;
+	uint32_t n_spaces;
 	CameraRec cam;
 	SunRec sun;
 };
@@ -47,6 +52,7 @@ struct RenderParams {
 struct PassBuffers {
 	float4* queues;                   // [n_wave_slots][kQueueFloat4PerWave]
 	float4* sample_rad;               // [pass_spp][n_pixels]
+	uint2* spill;                     // [n_wave_slots][kSpillWords]: traversal-stack overflow, lane-interleaved
 	uint32_t* chunk_counter;          // zeroed before each pass
 	unsigned long long* ray_counter;  // accumulates
 };
@@ -57,6 +63,7 @@ struct IntersectArgs {
 	float* distance; int32_t* surface; int32_t* triangle;
 	float *b0, *b1, *b2;
 	float *px, *py, *pz, *nx, *ny, *nz, *u, *v;  // optional groups (nullptr = skip)
+	uint2* spill;                                // [grid * waves per block][kSpillWords]
 };
 
 hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, bool lds, size_t lds_bytes, int grid,

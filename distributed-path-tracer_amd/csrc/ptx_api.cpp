@@ -16,6 +16,9 @@
 #include "kernels.hpp"
 
 using namespace ptx;
+#ifdef PTX_STAMP
+namespace ptx { void diag_dump(); }
+#endif
 
 namespace {
 
@@ -56,14 +59,14 @@ struct ptx_ctx {
 	hipStream_t stream = nullptr;
 	int n_cu = 0;
 	std::mutex mu;
-	DevBuf queues, sample_rad, counters, stage_a, stage_b;
+	DevBuf queues, sample_rad, counters, spill, stage_a, stage_b;
 	std::vector<hipEvent_t> events;
 };
 
 struct ptx_scene {
 	ptx_ctx* ctx = nullptr;
 	FlatScene host;
-	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr, d_shade;
+	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr, d_shade, d_visits, d_spaces, d_model_space;
 	DevScene dev{};
 	bool lds = false;
 	size_t lds_bytes = 0;
@@ -92,6 +95,9 @@ int upload_scene(ptx_scene* sc) {
 	HIP_TRY(up(sc->d_tris, h.tris.data(), h.tris.size() * 48, h.tris.size() * 48));
 	HIP_TRY(up(sc->d_vattr, h.vattr.data(), h.vattr.size() * 32, h.vattr.size() * 32));
 	HIP_TRY(up(sc->d_shade, h.shade.data(), h.shade.size() * sizeof(ShadeRec), h.shade.size() * sizeof(ShadeRec)));
+	HIP_TRY(up(sc->d_visits, h.visits.data(), h.visits.size() * sizeof(VisitRec), h.visits.size() * sizeof(VisitRec)));
+	HIP_TRY(up(sc->d_spaces, h.spaces.data(), h.spaces.size() * sizeof(SpaceRec), h.spaces.size() * sizeof(SpaceRec)));
+	HIP_TRY(up(sc->d_model_space, h.model_space.data(), h.model_space.size() * 4, h.model_space.size() * 4));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	DevScene& d = sc->dev;
 	d.models = (const ModelRec*)sc->d_models.p;
@@ -102,6 +108,10 @@ int upload_scene(ptx_scene* sc) {
 	d.tris = (const float4*)sc->d_tris.p;
 	d.vattr = (const float4*)sc->d_vattr.p;
 	d.shade = (const ShadeRec*)sc->d_shade.p;
+	d.visits = (const VisitRec*)sc->d_visits.p;
+	d.spaces = (const SpaceRec*)sc->d_spaces.p;
+	d.model_space = (const uint32_t*)sc->d_model_space.p;
+	d.n_spaces = (uint32_t)h.spaces.size();
 	d.n_surfaces = (uint32_t)h.surfaces.size();
 	d.any_alpha = h.any_alpha ? 1u : 0u;
 	d.n_models = (int32_t)h.models.size();
@@ -110,7 +120,7 @@ int upload_scene(ptx_scene* sc) {
 	d.n_tris = (uint32_t)h.tris.size();
 	d.cam = h.camera;
 	d.sun = h.sun;
-	sc->lds_bytes = h.tris.size() * 48 + h.shade.size() * sizeof(ShadeRec) + pad16(h.kd_nodes.size() * 8) + pad16(h.kd_refs.size() * 4);
+	sc->lds_bytes = h.tris.size() * 48 + h.shade.size() * (sizeof(ShadeRec) + sizeof(VisitRec)) + pad16(h.kd_nodes.size() * 8) + pad16(h.kd_refs.size() * 4);
 	sc->lds = sc->lds_bytes <= kLdsBudget;
 	return PTX_OK;
 }
@@ -122,7 +132,7 @@ int finish_scene(ptx_ctx* ctx, ptx_scene* sc, ptx_scene** out) {
 		int rc = upload_scene(sc);
 		if (rc != PTX_OK) { delete sc; return rc; }
 	} else {
-		sc->lds_bytes = sc->host.tris.size() * 48 + sc->host.shade.size() * sizeof(ShadeRec) + pad16(sc->host.kd_nodes.size() * 8) + pad16(sc->host.kd_refs.size() * 4);
+		sc->lds_bytes = sc->host.tris.size() * 48 + sc->host.shade.size() * (sizeof(ShadeRec) + sizeof(VisitRec)) + pad16(sc->host.kd_nodes.size() * 8) + pad16(sc->host.kd_refs.size() * 4);
 		sc->lds = sc->lds_bytes <= kLdsBudget;
 	}
 	*out = sc;
@@ -163,7 +173,7 @@ void ptx_ctx_destroy(ptx_ctx* c) {
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
 	for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
-	c->queues.release(); c->sample_rad.release(); c->counters.release(); c->stage_a.release(); c->stage_b.release();
+	c->queues.release(); c->spill.release(); c->sample_rad.release(); c->counters.release(); c->stage_a.release(); c->stage_b.release();
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -220,6 +230,7 @@ int ptx_scene_from_arrays(ptx_ctx* ctx, const ptx_scene_desc* d, ptx_scene** out
 		for (uint32_t m = 0; m < d->n_models; m++) {
 			int32_t f = h.model_surf[2 * m], n = h.model_surf[2 * m + 1];
 			if (f < 0 || n < 0 || (uint32_t)(f + n) > d->n_surfaces) throw Error{PTX_ERR_INVALID, "model surface range out of bounds"};
+			if (f != (m ? h.model_surf[2 * m - 2] + h.model_surf[2 * m - 1] : 0)) throw Error{PTX_ERR_INVALID, "model surface ranges must be consecutive, in model order"};
 			h.model_names.push_back("model" + std::to_string(m));
 		}
 		h.materials_raw.assign(d->materials, d->materials + 11 * (size_t)d->n_surfaces);
@@ -242,7 +253,7 @@ void ptx_scene_destroy(ptx_scene* sc) {
 		(void)hipSetDevice(sc->ctx->device);
 		(void)hipStreamSynchronize(sc->ctx->stream);
 		sc->d_models.release(); sc->d_surfaces.release(); sc->d_materials.release(); sc->d_nodes.release();
-		sc->d_refs.release(); sc->d_tris.release(); sc->d_vattr.release(); sc->d_shade.release();
+		sc->d_refs.release(); sc->d_tris.release(); sc->d_vattr.release(); sc->d_shade.release(); sc->d_visits.release(); sc->d_spaces.release(); sc->d_model_space.release();
 	}
 	delete sc;
 }
@@ -336,6 +347,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 	HIP_TRY(c->queues.ensure(n_slots * (size_t)kQueueFloat4PerWave * sizeof(float4)));
 	HIP_TRY(c->sample_rad.ensure((size_t)pass_spp * n_pixels * sizeof(float4)));
 	HIP_TRY(c->counters.ensure(64));
+	HIP_TRY(c->spill.ensure(n_slots * (size_t)kSpillWords * sizeof(uint2)));
 	uint32_t* chunk_counter = (uint32_t*)c->counters.p;
 	unsigned long long* ray_counter = (unsigned long long*)((char*)c->counters.p + 16);
 	HIP_TRY(hipMemsetAsync(c->counters.p, 0, 64, c->stream));
@@ -355,7 +367,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 			HIP_TRY(hipEventCreate(&ev));
 			c->events.push_back(ev);
 		}
-	PassBuffers B{(float4*)c->queues.p, (float4*)c->sample_rad.p, chunk_counter, ray_counter};
+	PassBuffers B{(float4*)c->queues.p, (float4*)c->sample_rad.p, (uint2*)c->spill.p, chunk_counter, ray_counter};
 	for (uint32_t p = 0; p < n_pass; p++) {
 		RenderParams P{};
 		P.W = cfg->W; P.H = cfg->H; P.x0 = x0; P.y0 = y0; P.w = w; P.h = h;
@@ -381,6 +393,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 #ifdef PTX_STAMP
 		unsigned long long ph[2] = {0, 0};
 		HIP_TRY(hipMemcpy(ph, ray_counter + 1, 16, hipMemcpyDeviceToHost));
+		diag_dump();
 		fprintf(stderr, "[PTX_STAMP] wave-cycles extend=%llu shade=%llu  (extend share %.1f%%)\n", ph[0], ph[1], 100.0 * ph[0] / (double)(ph[0] + ph[1]));
 #endif
 		stats->samples = (uint64_t)cfg->spp * n_pixels;
@@ -433,6 +446,8 @@ int ptx_intersect_batch(ptx_scene* sc, const ptx_rays* r, size_t n, const ptx_hi
 		if (hh->u) { A.u = o + k * n; A.v = o + (k + 1) * n; }
 	}
 	const int grid = (int)std::min<size_t>((size_t)c->n_cu, (n + kBlock - 1) / kBlock);
+	HIP_TRY(c->spill.ensure((size_t)c->n_cu * (kBlock / 64) * (size_t)kSpillWords * sizeof(uint2)));
+	A.spill = (uint2*)c->spill.p;
 	HIP_TRY(launch_intersect(sc->dev, A, sc->lds, sc->lds_bytes, grid, c->stream));
 	if (!dev) {
 		void* dst[14] = {hh->distance, hh->surface, hh->triangle, hh->b0, hh->b1, hh->b2, hh->px, hh->py, hh->pz, hh->nx, hh->ny, hh->nz, hh->u, hh->v};

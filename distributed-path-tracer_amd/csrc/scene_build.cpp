@@ -254,6 +254,28 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 		memcpy(mr.bmin, b.lo, 12);
 		memcpy(mr.bmax, b.hi, 12);
 	}
+	// distinct ray spaces (bitwise-equal inverse transforms) and the per-surface visit list
+	s.spaces.clear();
+	s.model_space.assign(n_models, 0);
+	for (size_t mi = 0; mi < n_models; mi++) {
+		SpaceRec sp;
+		memcpy(sp.inv_basis, s.models[mi].inv_basis, 36);
+		memcpy(sp.inv_origin, s.models[mi].inv_origin, 12);
+		size_t k = 0;
+		for (; k < s.spaces.size(); k++) if (!memcmp(&s.spaces[k], &sp, sizeof sp)) break;
+		if (k == s.spaces.size()) s.spaces.push_back(sp);
+		s.model_space[mi] = (uint32_t)k;
+	}
+	s.visits.assign(n_surf, VisitRec{});
+	for (size_t mi = 0; mi < n_models; mi++)
+		for (int32_t k = 0; k < s.models[mi].n_surfaces; k++) {
+			const size_t si = (size_t)s.models[mi].first_surface + k;
+			VisitRec& v = s.visits[si];
+			memcpy(v.bmin, s.surfaces[si].bmin, 12);
+			memcpy(v.bmax, s.surfaces[si].bmax, 12);
+			v.kd_root = s.surfaces[si].kd_root;
+			v.model_space = (uint32_t)mi | (s.model_space[mi] << 24);
+		}
 	s.shade.assign(n_surf, ShadeRec{});
 	for (size_t mi = 0; mi < n_models; mi++)
 		for (int32_t k = 0; k < s.models[mi].n_surfaces; k++) {
