@@ -31,6 +31,17 @@ B_RAY_CORNELL = 188 + 8 * 3.44 + 40 * 11.82 + 192
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
 
 
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (FETCH_SIZE / WRITE_SIZE are collected
+    in separate rocprofv3 --pmc passes — tools/pmc_passes.sh — and cannot be read live here). None if no profile."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        return json.load(fh).get("traffic_bytes_per_launch")
+
+
 def cpu_baseline():
     """Time the reference's own renderer::render on the host cores: 1080p, 8 bounces, 1 spp (~10 s)."""
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
@@ -79,6 +90,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ptx = importlib.import_module("distributed-path-tracer_amd")
+    mg = importlib.import_module("distributed-path-tracer_amd.multigpu")
     ctx = ptx.Context(local_rank)
     scene = ptx.Scene.load_gltf(ctx, CORNELL)      # scene is uploaded to HBM here, outside the timed region
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
@@ -87,9 +99,8 @@ def main():
     def step(collect):
         accum.zero_()
         torch.cuda.synchronize()
-        _, st = scene.render(W, H, spp, BOUNCES, accum=accum, sample0=rank * spp, want_stats=True)  # syncs the ctx stream
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)   # RCCL over xGMI: framebuffer sum on rank 0
+        # this rank's sample range -> ptx_render (syncs the ctx stream) -> RCCL sum-reduce of the framebuffer onto rank 0
+        st = mg.render_sharded(scene, W, H, spp, BOUNCES, accum, rank, world, want_stats=True)
         if collect is not None:
             collect.append(st)
 
@@ -134,7 +145,8 @@ def main():
             "mrays_per_s": round(total_rays / dt / 1e6, 2),
             "rays_per_sample": round(total_rays / samples, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(),
+                         "algorithmic_bytes_per_launch": round(rays_per_launch * B_RAY_CORNELL),
                          "kernel": "k_render_pass<LDS>", "avg_launch_ms": round(kernel_ms, 4), "launches": launches,
                          "rays_per_launch": round(rays_per_launch), "bytes_per_ray": round(B_RAY_CORNELL, 2)},
         }

@@ -758,6 +758,301 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S, RenderParams
 	if (lane == 0 && rays) atomicAdd(B.ray_counter, (unsigned long long)rays);
 }
 
+// ------------------------------------------------------------------------------------ integrator kernel, cooperative form
+// Same estimator, same per-ray arithmetic, different schedule (scenes without sun light / alpha, with <= 64 surfaces
+// and <= 2 ray spaces; everything else runs k_render_pass above).
+//
+// Stream entry of a live path (SoA of float4 arrays, wave-private, kChunk entries per array):
+//   A0 = world dir.xyz, path id | A1 = T.xyz, L.x | A2 = L.y, L.z, surface mask (2 words)
+//   per ray space k: Bk0 = local origin.xyz, local dir.x | Bk1 = local dir.y, dir.z, 1/dir.x, 1/dir.y | Bk2 = 1/dir.z
+// i.e. the producer of a ray (camera generation or the shading of the previous vertex, both running with all lanes
+// busy) also does the ray's wave-uniform setup: local rays per space and the bit mask of surfaces whose boxes it meets.
+//
+// EXTEND then is one persistent loop per (chunk, depth): lanes pull rays from the stream as they finish (ballot +
+// prefix over the idle lanes, one load of the entry's traversal part), so a long traversal delays only its own lane.
+template <int NSPACE> struct LocalRays { V3 lo[NSPACE], ld[NSPACE], inv[NSPACE]; uint64_t mask; };
+
+template <int NSPACE>
+DEV void ray_setup(const DevScene& S, V3 o, V3 d, LocalRays<NSPACE>& r) {
+#pragma unroll
+	for (int k = 0; k < NSPACE; k++) {
+		const SpaceRec& sp = S.spaces[k];
+		r.lo[k] = mulmv(sp.inv_basis, o) + mk(sp.inv_origin[0], sp.inv_origin[1], sp.inv_origin[2]);
+		r.ld[k] = normalize(mulmv(sp.inv_basis, d));
+		r.inv[k] = mk(1.0f / r.ld[k].x, 1.0f / r.ld[k].y, 1.0f / r.ld[k].z);
+	}
+	uint64_t mask = 0;
+	for (int m = 0; m < S.n_models; m++) {
+		const ModelRec& M = S.models[m];
+		const bool s1 = NSPACE > 1 && S.model_space[m] != 0;  // wave-uniform
+		const V3 mo = s1 ? r.lo[NSPACE - 1] : r.lo[0], mi = s1 ? r.inv[NSPACE - 1] : r.inv[0];
+		float nr, fr;
+		const bool mh = aabb_test_inv(M.bmin, M.bmax, mo, mi, nr, fr);
+		for (int k = 0; k < M.n_surfaces; k++) {
+			const SurfaceRec& sf = S.surfaces[M.first_surface + k];
+			const bool sh = mh && aabb_test_inv(sf.bmin, sf.bmax, mo, mi, nr, fr);
+			mask |= sh ? (1ull << (M.first_surface + k)) : 0ull;
+		}
+	}
+	r.mask = mask;
+}
+
+template <int NSPACE>
+DEV void entry_store(float4* q, uint32_t pos, V3 dw, uint32_t id, V3 T, V3 L, const LocalRays<NSPACE>& r) {
+	q[pos] = make_float4(dw.x, dw.y, dw.z, __uint_as_float(id));
+	q[kChunk + pos] = make_float4(T.x, T.y, T.z, L.x);
+	q[2 * kChunk + pos] = make_float4(L.y, L.z, __uint_as_float((uint32_t)r.mask), __uint_as_float((uint32_t)(r.mask >> 32)));
+#pragma unroll
+	for (int k = 0; k < NSPACE; k++) {
+		q[(3 + 3 * k) * kChunk + pos] = make_float4(r.lo[k].x, r.lo[k].y, r.lo[k].z, r.ld[k].x);
+		q[(4 + 3 * k) * kChunk + pos] = make_float4(r.ld[k].y, r.ld[k].z, r.inv[k].x, r.inv[k].y);
+		q[(5 + 3 * k) * kChunk + pos] = make_float4(r.inv[k].z, 0.f, 0.f, 0.f);
+	}
+}
+
+constexpr uint32_t kRefillMin = 12;  // refill when at least this many lanes are idle (or nothing else is runnable)
+
+template <bool LDS, int NSPACE>
+__global__ void __launch_bounds__(kBlock) k_render_pass_coop(DevScene S, RenderParams P, PassBuffers B) {
+	const Staged stg = stage_geometry<LDS>(S, g_smem);
+	const Geom g = stg.g;
+	const ShadeRec* shade = stg.shade;
+	const float4* visits = reinterpret_cast<const float4*>(stg.visits);
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave_slot = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	constexpr uint32_t kArrays = 3 + 3 * NSPACE;
+	float4* qbase = B.queues + (size_t)wave_slot * (kQueueFloat4PerWave);
+	float4* hbuf = qbase + 2u * kArrays * kChunk;
+	const Spill spill{B.spill + (size_t)wave_slot * (kSpillStack * 64) + lane};
+	uint64_t rays = 0;  // wave-uniform count
+
+	for (;;) {
+		uint32_t chunk = 0;
+		if (lane == 0) chunk = atomicAdd(B.chunk_counter, 1u);
+		chunk = __builtin_amdgcn_readfirstlane(chunk);
+		const uint64_t first = (uint64_t)chunk * kChunk;
+		if (first >= P.n_paths) break;
+		uint32_t n_in = (uint32_t)((P.n_paths - first) < (uint64_t)kChunk ? (P.n_paths - first) : kChunk);
+
+		// ---------------- GENERATE: camera rays of the chunk (renderer.cpp:359-370), with their setup
+		for (uint32_t base = 0; base < n_in; base += 64) {
+			const uint32_t i = base + lane;
+			if (i < n_in) {
+				const uint32_t id = (uint32_t)first + i;  // id within the pass: sample-major, pixel-minor
+				const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
+				const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
+				V3 o, d;
+				camera_ray(S, P, px, py, P.sample0 + s_local, o, d);
+				LocalRays<NSPACE> lr;
+				ray_setup<NSPACE>(S, o, d, lr);
+				entry_store<NSPACE>(qbase, i, d, id, mk(1, 1, 1), mk(0, 0, 0), lr);
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+		for (uint32_t depth = 0; depth < P.bounces && n_in > 0; depth++) {
+			float4* qin = qbase + (size_t)(depth & 1u) * (kArrays * kChunk);
+			float4* qout = qbase + (size_t)((depth + 1u) & 1u) * (kArrays * kChunk);
+			const bool last = depth + 1 == P.bounces;
+			rays += n_in;
+#ifdef PTX_STAMP
+			if (lane == 0) atomicAdd(g_diag + 4, (unsigned long long)n_in);
+#endif
+
+			// ---------------- EXTEND: persistent traversal, lanes refill from the stream
+			{
+				uint32_t next = 0;                       // wave-uniform: first stream entry not yet taken
+				uint32_t idx = 0;
+				uint32_t st = ST_DONE;
+				V3 lo[NSPACE], ld[NSPACE], inv[NSPACE];
+#pragma unroll
+				for (int k = 0; k < NSPACE; k++) { lo[k] = mk(0, 0, 0); ld[k] = mk(0, 0, 1); inv[k] = mk(0, 0, 0); }
+				uint64_t mask = 0;
+				int cur_model = -1, cur_surf = -1;
+				V3 co = mk(0, 0, 0), cd = mk(0, 0, 1);
+				float nt = -1.0f, nb1 = 0, nb2 = 0; uint32_t ntri = 0; int nsurf = -1;
+				float bdist = -1.0f, bb1 = 0, bb2 = 0; uint32_t btri = 0; int bsurf = -1;
+				uint32_t node = 0; float tmin = 0, tmax = 0, tfar = 0; int sp = 0;
+				uint32_t n0 = 0, n1 = 0, n2 = 0; float m0 = 0, m1 = 0, m2 = 0;
+				uint32_t rcur = 0, rend = 0; float lt = -1.0f, lb1 = 0, lb2 = 0; uint32_t ltri = 0;
+
+				for (;;) {
+					const bool want_tri = rcur < rend;
+					const bool idle = st == ST_DONE;
+					const bool want_adv = !want_tri && !idle;
+					const uint64_t mt = __ballot(want_tri), ma = __ballot(want_adv), mi = __ballot(idle);
+					const uint32_t ct = (uint32_t)__popcll(mt), ca = (uint32_t)__popcll(ma), ci = (uint32_t)__popcll(mi);
+#ifdef PTX_STAMP
+					if (lane == 0) {
+						const bool rf = next < n_in && ci != 0 && (ci >= kRefillMin || (mt | ma) == 0);
+						if (rf) { atomicAdd(g_diag + 5, 1ull); atomicAdd(g_diag + 6, (unsigned long long)ci); }
+						else if ((mt | ma) != 0) {
+							if (ct >= ca) { atomicAdd(g_diag + 0, 1ull); atomicAdd(g_diag + 2, (unsigned long long)ct); }
+							else { atomicAdd(g_diag + 1, 1ull); atomicAdd(g_diag + 3, (unsigned long long)ca); }
+						}
+					}
+#endif
+					if (next < n_in && ci != 0 && (ci >= kRefillMin || (mt | ma) == 0)) {
+						// ---------------- REFILL: idle lanes take the next stream entries
+						if (idle) {
+							const uint32_t my = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
+							if (my < n_in) {
+								const float4 a2 = qin[2 * kChunk + my];
+								mask = (uint64_t)__float_as_uint(a2.z) | ((uint64_t)__float_as_uint(a2.w) << 32);
+#pragma unroll
+								for (int k = 0; k < NSPACE; k++) {
+									const float4 b0 = qin[(3 + 3 * k) * kChunk + my], b1 = qin[(4 + 3 * k) * kChunk + my], b2 = qin[(5 + 3 * k) * kChunk + my];
+									lo[k] = mk(b0.x, b0.y, b0.z); ld[k] = mk(b0.w, b1.x, b1.y); inv[k] = mk(b1.z, b1.w, b2.x);
+								}
+								idx = my;
+								st = ST_NEXT; cur_model = -1; nt = -1.0f; bdist = -1.0f; bsurf = -1; btri = 0; bb1 = 0; bb2 = 0;
+							}
+						}
+						next += ci;
+						continue;
+					}
+					if ((mt | ma) == 0) break;
+					if (ct >= ca) {
+						// ---------------- TRI: one leaf triangle (mesh.cpp:381-389; ties keep the first)
+						if (want_tri) {
+							const uint32_t ti = g.refs[rcur];
+							const float4 A = g.tris[3 * ti], Bv = g.tris[3 * ti + 1], C = g.tris[3 * ti + 2];
+							float al, be, ga;
+							const float t = tri_test(mk(A.x, A.y, A.z), mk(Bv.x, Bv.y, Bv.z), mk(C.x, C.y, C.z), co, cd, al, be, ga);
+							if (t >= 0 && t <= tmax && (t < lt || !(lt >= 0))) { lt = t; lb1 = be; lb2 = ga; ltri = ti; }
+							rcur++;
+						}
+					} else if (want_adv) {
+						// ---------------- ADVANCE
+						if (st == ST_LEAF) {
+							if (lt >= 0) {   // the leaf produced a hit: mesh::intersect returns it (mesh.cpp:397-401)
+								if (lt < nt || !(nt >= 0)) { nt = lt; nb1 = lb1; nb2 = lb2; ntri = ltri; nsurf = cur_surf; }   // model.cpp:45-49
+								st = ST_NEXT;
+							} else st = ST_POP;
+						}
+						if (st == ST_POP) {
+							if (sp == 0) st = ST_NEXT;
+							else {
+								sp--;
+								node = n0; tmin = m0;
+								n0 = n1; m0 = m1; n1 = n2; m1 = m2;
+								if (sp >= kRegStack) spill_get(spill, sp - kRegStack, n2, m2);
+								tmax = sp > 0 ? m0 : tfar;
+								st = ST_NODE;
+							}
+						}
+						if (st == ST_NEXT) {
+							const bool more = mask != 0;
+							const int s = more ? (int)__builtin_ctzll(mask) : 0;
+							uint32_t ms = 0; float4 v0 = make_float4(0, 0, 0, 0), v1 = v0;
+							if (more) { v0 = visits[2 * s]; v1 = visits[2 * s + 1]; ms = __float_as_uint(v1.w); }
+							const int model = more ? (int)(ms & 0xFFFFFFu) : -2;
+							if (model != cur_model) {
+								if (nt >= 0) {   // close the model: local -> world distance (model.cpp:62-63), then renderer.cpp:663-669
+									const ShadeRec& R = shade[nsurf];
+									const float wd = length(mulmv(R.basis, cd * nt));
+									if (wd >= 0 && (wd < bdist || !(bdist >= 0))) { bdist = wd; bsurf = nsurf; btri = ntri; bb1 = nb1; bb2 = nb2; }
+								}
+								nt = -1.0f;
+								cur_model = model;
+							}
+							if (!more) {
+								hbuf[idx] = make_float4(__int_as_float(bsurf), __uint_as_float(btri), bb1, bb2);
+								st = ST_DONE;
+							} else {
+								mask &= mask - 1;
+								cur_surf = s;
+								const bool s1 = NSPACE > 1 && (ms >> 24) != 0;
+								co = s1 ? lo[NSPACE - 1] : lo[0];
+								cd = s1 ? ld[NSPACE - 1] : ld[0];
+								const V3 civ = s1 ? inv[NSPACE - 1] : inv[0];
+								const float bmn[3] = {v0.x, v0.y, v0.z}, bmx[3] = {v1.x, v1.y, v1.z};
+								float nr, fr;
+								aabb_test_inv(bmn, bmx, co, civ, nr, fr);   // the hit is known from the mask; the distances are needed
+								node = __float_as_uint(v0.w); tmin = nr; tmax = fr; tfar = fr; sp = 0;
+								st = ST_NODE;
+							}
+						}
+						// descend to a leaf (mesh.cpp:313-370): the lanes of this section loop together
+						while (st == ST_NODE) {
+#ifdef PTX_STAMP
+							if (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(true) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(true), 0u)) == 0) atomicAdd(g_diag + 7, 1ull);
+#endif
+							const uint2 nd = g.nodes[node];
+							if ((nd.y & 3u) == KD_LEAF) {
+								rcur = nd.x; rend = nd.x + (nd.y >> 2);
+								lt = -1.0f;
+								st = ST_LEAF;
+							} else {
+								const uint32_t axis = nd.y & 3u;
+								const float split = __uint_as_float(nd.x);
+								const float oa = sel3(co, axis), da = sel3(cd, axis);
+								const float split_dist = (split - oa) / da;
+								const bool has_l = nd.y & 4u, has_r = nd.y & 8u;
+								const uint32_t li = nd.y >> 4, ri = li + (has_l ? 1u : 0u);
+								const bool left_first = oa < split;
+								const uint32_t first_c = left_first ? li : ri, second = left_first ? ri : li;
+								const bool has_first = left_first ? has_l : has_r, has_second = left_first ? has_r : has_l;
+								bool has_next;
+								if (split_dist < 0 || split_dist > tmax) { node = first_c; has_next = has_first; }
+								else if (split_dist < tmin) { node = second; has_next = has_second; }
+								else {
+									if (has_second && sp < kRegStack + kSpillStack) {
+										if (sp >= kRegStack) spill_put(spill, sp - kRegStack, n2, m2);
+										n2 = n1; m2 = m1; n1 = n0; m1 = m0; n0 = second; m0 = split_dist;
+										sp++;
+									}
+									node = first_c; has_next = has_first;
+									tmax = split_dist;
+								}
+								if (!has_next) st = ST_POP;
+							}
+						}
+					}
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+			// ---------------- SHADE + wave-level stream compaction (+ setup of the next ray)
+			uint32_t n_out = 0;
+			for (uint32_t base = 0; base < n_in; base += 64) {
+				const uint32_t i = base + lane;
+				const bool active = i < n_in;
+				V3 o = {0, 0, 0}, d = {0, 0, 1}, T = {1, 1, 1}, L = {0, 0, 0};
+				uint32_t id = 0;
+				bool alive = false;
+				if (active) {
+					const float4 a0 = qin[i], a1 = qin[kChunk + i], a2 = qin[2 * kChunk + i], hq = hbuf[i];
+					d = mk(a0.x, a0.y, a0.z); id = __float_as_uint(a0.w);
+					T = mk(a1.x, a1.y, a1.z); L = mk(a1.w, a2.x, a2.y);
+					SceneHit h;
+					h.dist = 0; h.surface = __float_as_int(hq.x); h.tri = __float_as_uint(hq.y); h.b1 = hq.z; h.b2 = hq.w;
+					const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
+					const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
+					uint32_t unused_rays = 0;
+					alive = shade_vertex<false, false>(S, g, shade, P, py * P.W + px, P.sample0 + s_local, depth, h, o, d, T, L, unused_rays, spill);
+					if (last) alive = false;  // trace(0, ..) returns black: renderer.cpp:438-439
+					if (!alive) B.sample_rad[id] = make_float4(L.x, L.y, L.z, 1.0f);
+				}
+				const uint64_t mk_alive = __ballot(alive);
+				if (alive) {
+					const uint32_t pos = n_out + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk_alive >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk_alive, 0u));
+					LocalRays<NSPACE> lr;
+					ray_setup<NSPACE>(S, o, d, lr);
+					entry_store<NSPACE>(qout, pos, d, id, T, L, lr);
+				}
+				n_out += (uint32_t)__popcll(mk_alive);
+			}
+			n_in = n_out;
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		}
+	}
+	if (lane == 0 && rays) atomicAdd(B.ray_counter, (unsigned long long)rays);
+}
+
 // Adds the pass's samples of each pixel, in sample order, into the accumulation buffer (sums).
 __global__ void k_resolve(const float4* __restrict__ sample_rad, float4* __restrict__ accum, uint32_t n_pixels, uint32_t pass_spp) {
 	uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -841,13 +1136,28 @@ static hipError_t launch_pass_variant(const DevScene& S, const RenderParams& P, 
 	hipLaunchKernelGGL((k_render_pass<LDS, SUN, ALPHA, NSPACE>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B);
 	return hipGetLastError();
 }
+template <bool LDS, int NSPACE>
+static hipError_t launch_coop(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
+	if (LDS) {
+		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass_coop<LDS, NSPACE>), lds_bytes);
+		if (e != hipSuccess) return e;
+	}
+	hipLaunchKernelGGL((k_render_pass_coop<LDS, NSPACE>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B);
+	return hipGetLastError();
+}
 template <bool LDS, bool SUN, bool ALPHA>
 static hipError_t launch_pass_space(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
 	// wave-cooperative traversal needs the surface mask in 64 bits and the local rays of all spaces in registers
-	static const bool force_simple = getenv("PTX_FORCE_SIMPLE") != nullptr;  // experiments: per-lane traversal everywhere
+	// The cooperative kernel is bit-identical but not yet faster than the per-lane one on Cornell (577 vs 610 Msamples/s):
+	// it is selected with PTX_COOP=1 until it wins.
+	static const bool force_simple = getenv("PTX_COOP") == nullptr;
 	const bool fast = !force_simple && S.n_surfaces <= (uint32_t)kMaxFastSurfaces && S.n_spaces <= (uint32_t)kMaxFastSpaces;
-	if (fast && S.n_spaces <= 1) return launch_pass_variant<LDS, SUN, ALPHA, 1>(S, P, B, lds_bytes, grid, stream);
-	if (fast) return launch_pass_variant<LDS, SUN, ALPHA, 2>(S, P, B, lds_bytes, grid, stream);
+	if constexpr (!SUN && !ALPHA) {
+		if (fast) {
+			if (S.n_spaces <= 1) return launch_coop<LDS, 1>(S, P, B, lds_bytes, grid, stream);
+			return launch_coop<LDS, 2>(S, P, B, lds_bytes, grid, stream);
+		}
+	}
 	return launch_pass_variant<LDS, SUN, ALPHA, 0>(S, P, B, lds_bytes, grid, stream);
 }
 
@@ -870,8 +1180,9 @@ hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const Pa
 void diag_dump() {
 	unsigned long long h[8];
 	if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof h) != hipSuccess) return;
-	fprintf(stderr, "[PTX_STAMP] extend64 calls=%llu  per call: tri trips %.2f (%.1f lanes), adv trips %.2f (%.1f lanes)\n", h[4],
-	        (double)h[0] / h[4], (double)h[2] / (h[0] ? h[0] : 1), (double)h[1] / h[4], (double)h[3] / (h[1] ? h[1] : 1));
+	const double per64 = h[4] / 64.0;
+	fprintf(stderr, "[PTX_STAMP] rays=%llu  per 64 rays: tri trips %.2f (%.1f lanes), adv trips %.2f (%.1f lanes), refill trips %.2f (%.1f lanes), node-loop iters %.2f\n", h[4],
+	        h[0] / per64, (double)h[2] / (h[0] ? h[0] : 1), h[1] / per64, (double)h[3] / (h[1] ? h[1] : 1), h[5] / per64, (double)h[6] / (h[5] ? h[5] : 1), h[7] / per64);
 }
 #endif
 hipError_t launch_resolve(const float4* sample_rad, float4* accum, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream) {

@@ -1,0 +1,47 @@
+"""Worker for tests/test_multigpu_gloo.py: one rank of a world_size-N gloo job (CPU).
+The product's multi-GPU host logic (multigpu.render_sharded / reduce_accum) runs unchanged; the GPU scene is
+replaced by an oracle-backed stand-in with the same .render signature (test infrastructure, CPU)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pt_oracle as ora  # noqa: E402
+
+mg = importlib.import_module("distributed-path-tracer_amd.multigpu")
+CORNELL = os.path.join(ROOT, "scenes", "cornell-box", "cornell.gltf")
+
+
+class OracleScene:
+    def __init__(self):
+        self.s = ora.OracleScene(ora.load_gltf(CORNELL))
+
+    def render(self, W, H, spp, bounces, accum=None, sample0=0, **kw):
+        smp = self.s.render_samples(ora.make_cfg(W, H, spp, bounces, sample0=sample0), threads=2)   # [H,W,spp,3]
+        a = accum.numpy()
+        for k in range(spp):                       # sums in sample order, like k_resolve
+            a[..., :3] += smp[:, :, k]
+            a[..., 3] += 1.0
+        return accum, {"rays": 0, "samples": W * H * spp}
+
+
+def main():
+    out = sys.argv[1]
+    W, H, spp, b = 40, 24, 3, 4
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    accum = torch.zeros((H, W, 4), dtype=torch.float32)
+    mg.render_sharded(OracleScene(), W, H, spp, b, accum, rank, world)
+    if rank == 0:
+        np.save(out, accum.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
