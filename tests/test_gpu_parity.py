@@ -220,3 +220,19 @@ def test_device_buffers_via_torch(scene, ctx):
     ctx.tonemap_encode(dev, W, H, spp, out=out8)
     ctx.synchronize()
     np.testing.assert_array_equal(out8.cpu().numpy(), ctx.tonemap_encode(host, W, H, spp))
+
+
+def test_cpp_host_cli(cornell_oracle, ora, tmp_path):
+    """The C++ mirror of core::renderer (host/ptx_renderer.hpp) driven by host/render_main.cpp: PNG vs the oracle."""
+    import os
+    import subprocess
+    from PIL import Image
+    from conftest import ROOT
+    cli = os.path.join(ROOT, "distributed-path-tracer_amd", "ptx_render_cli")
+    out = str(tmp_path / "cli.png")
+    r = subprocess.run([cli, CORNELL, out, "128", "72", "8", "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    img = np.array(Image.open(out))
+    assert img.shape == (72, 128, 4)
+    mean, _ = cornell_oracle.render(ora.make_cfg(128, 72, 8, 4), threads=0)
+    assert ora.psnr8(img, ora.tonemap_write(mean)) >= 40.0

@@ -134,3 +134,18 @@ def test_reference_png_fixture_decodes(gold_vec):
     from conftest import GOLD
     im = np.array(Image.open(os.path.join(GOLD, "cornell_ref_64x64_16spp_4b.png")))
     assert im.shape == (64, 64, 4) and (im[..., 3] == 255).all()
+
+
+def test_cpp_host_cli_fails_loudly_without_gpu(tmp_path):
+    """The C++ host over the C ABI (host/ptx_renderer.hpp) has no CPU path: on a GPU-less box it must exit non-zero."""
+    import subprocess
+    import torch
+    from conftest import ROOT
+    cli = os.path.join(ROOT, "distributed-path-tracer_amd", "ptx_render_cli")
+    if not os.path.exists(cli):
+        pytest.skip("CLI not built")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; covered by the gpu tests")
+    r = subprocess.run([cli, CORNELL, str(tmp_path / "o.png"), "16", "16", "1", "1"], capture_output=True, text=True)
+    assert r.returncode == 2 and "no HIP device" in r.stderr
+    assert not (tmp_path / "o.png").exists()
