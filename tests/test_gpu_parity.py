@@ -236,3 +236,67 @@ def test_cpp_host_cli(cornell_oracle, ora, tmp_path):
     assert img.shape == (72, 128, 4)
     mean, _ = cornell_oracle.render(ora.make_cfg(128, 72, 8, 4), threads=0)
     assert ora.psnr8(img, ora.tonemap_write(mean)) >= 40.0
+
+
+# ---------------------------------------------------------------------------- scenes beyond the Cornell asset
+def _proc():
+    import importlib
+    return importlib.import_module("distributed-path-tracer_amd.procedural")
+
+
+def _scene_parity(ptx, ctx, ora, d, W, H, spp, b, n_rays=60_000, seed=11):
+    from conftest import oracle_from_dict, product_from_dict
+    s = product_from_dict(ptx, ctx, d)
+    o = oracle_from_dict(ora, d)
+    cfg = ora.make_cfg(W, H, 1, b)
+    prim = o.primary_rays(cfg, 0).reshape(-1, 6)
+    out, idx = o.intersect(prim)
+    rng = np.random.default_rng(seed)
+    hit = idx >= 0
+    k = min(n_rays, int(hit.sum()))
+    sel = rng.choice(np.flatnonzero(hit), k, replace=True)
+    dd = rng.standard_normal((k, 3)).astype(np.float32)
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True).astype(np.float32)
+    dd = np.where((dd * out[sel, 11:14]).sum(1, keepdims=True) < 0, -dd, dd).astype(np.float32)
+    sec = np.concatenate([out[sel, :3] + out[sel, 11:14] * np.float32(1e-4), dd], 1).astype(np.float32)
+    rays = np.concatenate([prim, sec])
+    out, idx = o.intersect(rays)
+    hits = s.intersect(rays[:, :3], rays[:, 3:])
+    _check_hits(hits, out, idx)
+    ref = o.render_samples(ora.make_cfg(W, H, spp, b), threads=0)
+    got = np.zeros_like(ref)
+    for kk in range(spp):
+        a, _ = s.render(W, H, 1, b, sample0=kk)
+        got[:, :, kk] = a[..., :3]
+    err = np.abs(got - ref).max(-1) / np.maximum(np.abs(ref).max(-1), 1e-3)
+    assert (err < 1e-3).mean() > 0.995, f"{(err < 1e-3).mean():.4%} of samples agree"
+    return s, o
+
+
+@pytest.mark.parametrize("level", [2, 3])          # level 2 fits one CU's LDS (LDS kernels), level 3 does not (global-memory kernels)
+@pytest.mark.parametrize("sun,alpha", [(True, True), (True, False), (False, True), (False, False)])
+def test_plaza_sun_and_alpha_variants(ptx, ctx, ora, sun, alpha, level):
+    """Directional light NEE + shadow rays (renderer.cpp:498-564), opacity and shadow-catcher pass-through
+    (renderer.cpp:466-472,513-519,560-561), scaled/translated models, two ray spaces: all four kernel variants."""
+    d = _proc().plaza_scene(level=level, sun=sun, alpha=alpha)
+    s, _ = _scene_parity(ptx, ctx, ora, d, 80, 45, 4, 5)
+    info = s.info()
+    assert info["has_sun"] == int(sun) and info["lds_resident"] == int(level == 2)
+
+
+def test_config3_class_mesh_not_lds_resident(ptx, ctx, ora, cornell_arrays):
+    """BASELINE config 3 class: ~80k-triangle mesh in the Cornell room (geometry 9 MB: traversal from L2/HBM, not LDS)."""
+    c = dict(model_xform=cornell_arrays.model_xform, model_surf=cornell_arrays.model_surf, surf_range=cornell_arrays.surf_range,
+             vertices=cornell_arrays.vertices, triangles=cornell_arrays.triangles, materials=cornell_arrays.materials,
+             camera=cornell_arrays.camera)
+    d = _proc().cornell_with_mesh(c, level=6)
+    assert len(d["triangles"]) == 48 + 81920
+    s, o = _scene_parity(ptx, ctx, ora, d, 64, 36, 2, 8, n_rays=40_000)
+    info = s.info()
+    assert info["lds_resident"] == 0 and info["n_triangles"] == 81968 and info["kd_max_depth"] <= 26
+    # a 1080p tile of config 3's geometry against the oracle
+    W, H, spp, b = 1920, 1080, 2, 8
+    tile = (800, 500, 128, 72)
+    mean, _ = o.render(ora.make_cfg(W, H, spp, b, tile=tile), threads=0)
+    accum, _ = s.render(W, H, spp, b, tile=tile)
+    assert ora.psnr8(ctx.tonemap_encode(accum, tile[2], tile[3], spp), ora.tonemap_write(mean)) >= 40.0
