@@ -109,6 +109,7 @@ struct FlatScene {
 	std::vector<SpaceRec> spaces;        // distinct world->local transforms
 	std::vector<uint32_t> model_space;   // per model
 	std::vector<VisitRec> visits;        // per surface
+	std::vector<uint32_t> key_surfaces;  // up to 8 surfaces with the most leaf references (sort key of the sorted kernel)
 	std::vector<KdNode> kd_nodes;
 	std::vector<uint32_t> kd_refs;       // global triangle ids
 	std::vector<TriRec> tris;

@@ -1053,6 +1053,193 @@ __global__ void __launch_bounds__(kBlock) k_render_pass_coop(DevScene S, RenderP
 	if (lane == 0 && rays) atomicAdd(B.ray_counter, (unsigned long long)rays);
 }
 
+// ------------------------------------------------------------------------------------ integrator kernel, mask-sorted form
+// The per-lane traversal of k_render_pass pays, for every group of 64 rays, the slowest lane of EVERY model any lane
+// touches: on Cornell a ray meets 2-3 of the 7 surface boxes, the wave meets all of them (37 % lane utilisation).
+// Here every live ray carries the bit mask of surfaces whose boxes it meets (computed by its producer, all lanes busy),
+// and before each EXTEND sweep the wave counting-sorts its chunk by an 8-bit key made of the mask bits of the most
+// expensive surfaces (LDS bins, ds_add_rtn; ~30 instructions per 64 rays). Lanes of one wave-iteration then share
+// their masks, whole models are skipped by the exec mask, and the leaf-triangle loops run with nearly full waves.
+// Arithmetic per ray is unchanged (same visiting order, same operations): results are bit-identical.
+// Stream entry (SoA of float4 arrays x kChunk): A0 = world dir, id | A1 = T, L.x | A2 = L.y, L.z, mask |
+//   per space k: (lo.xyz, ld.x), (ld.y, ld.z, inv.x, inv.y) | C = inv.z of space 0, 1
+template <int NSPACE>
+DEV void entry_store_s(float4* q, uint32_t pos, V3 dw, uint32_t id, V3 T, V3 L, const LocalRays<NSPACE>& r) {
+	q[pos] = make_float4(dw.x, dw.y, dw.z, __uint_as_float(id));
+	q[kChunk + pos] = make_float4(T.x, T.y, T.z, L.x);
+	q[2 * kChunk + pos] = make_float4(L.y, L.z, __uint_as_float((uint32_t)r.mask), __uint_as_float((uint32_t)(r.mask >> 32)));
+#pragma unroll
+	for (int k = 0; k < NSPACE; k++) {
+		q[(3 + 2 * k) * kChunk + pos] = make_float4(r.lo[k].x, r.lo[k].y, r.lo[k].z, r.ld[k].x);
+		q[(4 + 2 * k) * kChunk + pos] = make_float4(r.ld[k].y, r.ld[k].z, r.inv[k].x, r.inv[k].y);
+	}
+	q[(3 + 2 * NSPACE) * kChunk + pos] = make_float4(r.inv[0].z, r.inv[NSPACE - 1].z, 0.f, 0.f);
+}
+
+// closest hit with the surface mask: renderer::intersect / model::intersect order, boxes already tested
+template <int NSPACE>
+DEV void scene_traverse_masked(const DevScene& S, const Geom& g, const V3* lo, const V3* ld, const V3* inv, uint64_t mask,
+                               SceneHit& best, const Spill& spill) {
+	best.dist = -1.0f; best.surface = -1; best.tri = 0; best.b1 = 0; best.b2 = 0;
+	for (int m = 0; m < S.n_models; m++) {
+		const ModelRec& M = S.models[m];
+		const uint64_t mm = (mask >> M.first_surface) & (M.n_surfaces >= 64 ? ~0ull : ((1ull << M.n_surfaces) - 1ull));
+		if (mm == 0) continue;
+		const bool s1 = NSPACE > 1 && S.model_space[m] != 0;  // wave-uniform
+		const V3 mo = s1 ? lo[NSPACE - 1] : lo[0], md = s1 ? ld[NSPACE - 1] : ld[0], mi = s1 ? inv[NSPACE - 1] : inv[0];
+		MeshHit nearest;
+		nearest.t = -1.0f;
+		int hit_surface = -1;
+		for (int k = 0; k < M.n_surfaces; k++) {
+			if (!((mm >> k) & 1ull)) continue;
+			MeshHit h;
+			if (!mesh_traverse(g, S.surfaces[M.first_surface + k], mo, md, mi, h, spill)) continue;
+			if (h.t < nearest.t || !(nearest.t >= 0)) { nearest = h; hit_surface = M.first_surface + k; }
+		}
+		if (!(nearest.t >= 0)) continue;
+		const float wd = length(mulmv(M.basis, md * nearest.t));
+		if (!(wd >= 0)) continue;
+		if (wd < best.dist || !(best.dist >= 0)) { best.dist = wd; best.surface = hit_surface; best.tri = nearest.tri; best.b1 = nearest.b1; best.b2 = nearest.b2; }
+	}
+}
+
+template <bool LDS, int NSPACE>
+__global__ void __launch_bounds__(kBlock) k_render_pass_sorted(DevScene S, RenderParams P, PassBuffers B, uint32_t bins_offset) {
+	const Staged stg = stage_geometry<LDS>(S, g_smem);
+	const Geom g = stg.g;
+	const ShadeRec* shade = stg.shade;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave_in_block = threadIdx.x >> 6;
+	const uint32_t wave_slot = blockIdx.x * (kBlock / 64) + wave_in_block;
+	constexpr uint32_t kArrays = 4 + 2 * NSPACE;
+	float4* qbase = B.queues + (size_t)wave_slot * (kQueueFloat4PerWave);
+	float4* hbuf = qbase + 2u * kArrays * kChunk;
+	uint32_t* perm = reinterpret_cast<uint32_t*>(hbuf + kChunk);   // [kChunk]
+	uint32_t* tmp = perm + kChunk;                                 // [kChunk]
+	uint32_t* bins = reinterpret_cast<uint32_t*>(g_smem + bins_offset) + wave_in_block * 256u;   // this wave's 256 counters
+	const Spill spill{B.spill + (size_t)wave_slot * (kSpillStack * 64) + lane};
+	uint64_t rays = 0;  // wave-uniform count
+
+	for (;;) {
+		uint32_t chunk = 0;
+		if (lane == 0) chunk = atomicAdd(B.chunk_counter, 1u);
+		chunk = __builtin_amdgcn_readfirstlane(chunk);
+		const uint64_t first = (uint64_t)chunk * kChunk;
+		if (first >= P.n_paths) break;
+		uint32_t n_in = (uint32_t)((P.n_paths - first) < (uint64_t)kChunk ? (P.n_paths - first) : kChunk);
+
+		// ---------------- GENERATE: camera rays of the chunk (renderer.cpp:359-370), with their setup
+		for (uint32_t base = 0; base < n_in; base += 64) {
+			const uint32_t i = base + lane;
+			if (i < n_in) {
+				const uint32_t id = (uint32_t)first + i;  // id within the pass: sample-major, pixel-minor
+				const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
+				const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
+				V3 o, d;
+				camera_ray(S, P, px, py, P.sample0 + s_local, o, d);
+				LocalRays<NSPACE> lr;
+				ray_setup<NSPACE>(S, o, d, lr);
+				entry_store_s<NSPACE>(qbase, i, d, id, mk(1, 1, 1), mk(0, 0, 0), lr);
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+		for (uint32_t depth = 0; depth < P.bounces && n_in > 0; depth++) {
+			float4* qin = qbase + (size_t)(depth & 1u) * (kArrays * kChunk);
+			float4* qout = qbase + (size_t)((depth + 1u) & 1u) * (kArrays * kChunk);
+			const bool last = depth + 1 == P.bounces;
+			rays += n_in;
+
+			// ---------------- SORT: counting sort of the chunk by the surface-mask key
+			for (uint32_t k = lane; k < 256u; k += 64u) bins[k] = 0u;
+			for (uint32_t base = 0; base < n_in; base += 64) {
+				const uint32_t i = base + lane;
+				if (i < n_in) {
+					const float4 a2 = qin[2 * kChunk + i];
+					const uint64_t mask = (uint64_t)__float_as_uint(a2.z) | ((uint64_t)__float_as_uint(a2.w) << 32);
+					uint32_t key = 0;
+					for (uint32_t k = 0; k < S.n_key; k++) key |= (uint32_t)((mask >> S.key_surf[k]) & 1ull) << k;
+					const uint32_t r = atomicAdd(&bins[key], 1u);     // ds_add_rtn_u32: rank inside the bin
+					tmp[i] = key | (r << 8);
+				}
+			}
+			{   // exclusive scan of the 256 counters: 4 per lane + wave scan
+				const uint32_t c0 = bins[4 * lane], c1 = bins[4 * lane + 1], c2 = bins[4 * lane + 2], c3 = bins[4 * lane + 3];
+				const uint32_t tot = c0 + c1 + c2 + c3;
+				uint32_t incl = tot;
+				for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if ((int)lane >= off) incl += v; }
+				const uint32_t ex = incl - tot;
+				bins[4 * lane] = ex; bins[4 * lane + 1] = ex + c0; bins[4 * lane + 2] = ex + c0 + c1; bins[4 * lane + 3] = ex + c0 + c1 + c2;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			for (uint32_t base = 0; base < n_in; base += 64) {
+				const uint32_t i = base + lane;
+				if (i < n_in) { const uint32_t v = tmp[i]; perm[bins[v & 255u] + (v >> 8)] = i; }
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+			// ---------------- EXTEND in sorted order
+			for (uint32_t base = 0; base < n_in; base += 64) {
+				const uint32_t pos = base + lane;
+				if (pos < n_in) {
+					const uint32_t i = perm[pos];
+					const float4 a2 = qin[2 * kChunk + i], cz = qin[(3 + 2 * NSPACE) * kChunk + i];
+					const uint64_t mask = (uint64_t)__float_as_uint(a2.z) | ((uint64_t)__float_as_uint(a2.w) << 32);
+					V3 lo[NSPACE], ld[NSPACE], inv[NSPACE];
+#pragma unroll
+					for (int k = 0; k < NSPACE; k++) {
+						const float4 b0 = qin[(3 + 2 * k) * kChunk + i], b1 = qin[(4 + 2 * k) * kChunk + i];
+						lo[k] = mk(b0.x, b0.y, b0.z); ld[k] = mk(b0.w, b1.x, b1.y); inv[k] = mk(b1.z, b1.w, k == 0 ? cz.x : cz.y);
+					}
+					SceneHit h;
+					scene_traverse_masked<NSPACE>(S, g, lo, ld, inv, mask, h, spill);
+					hbuf[i] = make_float4(__int_as_float(h.surface), __uint_as_float(h.tri), h.b1, h.b2);
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+			// ---------------- SHADE + wave-level stream compaction (+ setup of the next ray)
+			uint32_t n_out = 0;
+			for (uint32_t base = 0; base < n_in; base += 64) {
+				const uint32_t i = base + lane;
+				const bool active = i < n_in;
+				V3 o = {0, 0, 0}, d = {0, 0, 1}, T = {1, 1, 1}, L = {0, 0, 0};
+				uint32_t id = 0;
+				bool alive = false;
+				if (active) {
+					const float4 a0 = qin[i], a1 = qin[kChunk + i], a2 = qin[2 * kChunk + i], hq = hbuf[i];
+					d = mk(a0.x, a0.y, a0.z); id = __float_as_uint(a0.w);
+					T = mk(a1.x, a1.y, a1.z); L = mk(a1.w, a2.x, a2.y);
+					SceneHit h;
+					h.dist = 0; h.surface = __float_as_int(hq.x); h.tri = __float_as_uint(hq.y); h.b1 = hq.z; h.b2 = hq.w;
+					const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
+					const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
+					uint32_t unused_rays = 0;
+					alive = shade_vertex<false, false>(S, g, shade, P, py * P.W + px, P.sample0 + s_local, depth, h, o, d, T, L, unused_rays, spill);
+					if (last) alive = false;  // trace(0, ..) returns black: renderer.cpp:438-439
+					if (!alive) B.sample_rad[id] = make_float4(L.x, L.y, L.z, 1.0f);
+				}
+				const uint64_t mk_alive = __ballot(alive);
+				if (alive) {
+					const uint32_t pos = n_out + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk_alive >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk_alive, 0u));
+					LocalRays<NSPACE> lr;
+					ray_setup<NSPACE>(S, o, d, lr);
+					entry_store_s<NSPACE>(qout, pos, d, id, T, L, lr);
+				}
+				n_out += (uint32_t)__popcll(mk_alive);
+			}
+			n_in = n_out;
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		}
+	}
+	if (lane == 0 && rays) atomicAdd(B.ray_counter, (unsigned long long)rays);
+}
+
 // Adds the pass's samples of each pixel, in sample order, into the accumulation buffer (sums).
 __global__ void k_resolve(const float4* __restrict__ sample_rad, float4* __restrict__ accum, uint32_t n_pixels, uint32_t pass_spp) {
 	uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1145,17 +1332,30 @@ static hipError_t launch_coop(const DevScene& S, const RenderParams& P, const Pa
 	hipLaunchKernelGGL((k_render_pass_coop<LDS, NSPACE>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B);
 	return hipGetLastError();
 }
+template <bool LDS, int NSPACE>
+static hipError_t launch_sorted(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
+	const size_t geo = LDS ? lds_bytes : 0, total = geo + (size_t)(kBlock / 64) * 256 * 4;
+	hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass_sorted<LDS, NSPACE>), total);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL((k_render_pass_sorted<LDS, NSPACE>), dim3(grid), dim3(kBlock), total, stream, S, P, B, (uint32_t)geo);
+	return hipGetLastError();
+}
 template <bool LDS, bool SUN, bool ALPHA>
 static hipError_t launch_pass_space(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
 	// wave-cooperative traversal needs the surface mask in 64 bits and the local rays of all spaces in registers
-	// The cooperative kernel is bit-identical but not yet faster than the per-lane one on Cornell (577 vs 610 Msamples/s):
-	// it is selected with PTX_COOP=1 until it wins.
-	static const bool force_simple = getenv("PTX_COOP") == nullptr;
-	const bool fast = !force_simple && S.n_surfaces <= (uint32_t)kMaxFastSurfaces && S.n_spaces <= (uint32_t)kMaxFastSpaces;
+	// Schedules of the same arithmetic (bit-identical results): "sorted" (default where it applies), "coop"
+	// (PTX_COOP=1: wave-cooperative state machine, experimental), per-lane (PTX_SIMPLE=1, and every scene the others do not cover).
+	static const bool want_coop = getenv("PTX_COOP") != nullptr, want_simple = getenv("PTX_SIMPLE") != nullptr;
+	const bool fast = !want_simple && S.n_surfaces <= (uint32_t)kMaxFastSurfaces && S.n_spaces <= (uint32_t)kMaxFastSpaces;
 	if constexpr (!SUN && !ALPHA) {
-		if (fast) {
+		if (fast && want_coop) {
 			if (S.n_spaces <= 1) return launch_coop<LDS, 1>(S, P, B, lds_bytes, grid, stream);
 			return launch_coop<LDS, 2>(S, P, B, lds_bytes, grid, stream);
+		}
+		const size_t sort_lds = (size_t)(kBlock / 64) * 256 * 4;
+		if (fast && (!LDS || lds_bytes + sort_lds <= 160 * 1024)) {
+			if (S.n_spaces <= 1) return launch_sorted<LDS, 1>(S, P, B, lds_bytes, grid, stream);
+			return launch_sorted<LDS, 2>(S, P, B, lds_bytes, grid, stream);
 		}
 	}
 	return launch_pass_variant<LDS, SUN, ALPHA, 0>(S, P, B, lds_bytes, grid, stream);

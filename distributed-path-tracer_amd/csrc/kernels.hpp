@@ -33,6 +33,8 @@ struct DevScene {
 	uint32_t n_surfaces, n_nodes, n_refs, n_tris;
 	uint32_t any_alpha;
 	uint32_t n_spaces;
+	uint32_t n_key;          // surfaces whose mask bits form the sort key (<= 8), most expensive first
+	uint32_t key_surf[8];
 	CameraRec cam;
 	SunRec sun;
 };

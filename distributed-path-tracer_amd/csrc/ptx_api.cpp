@@ -112,6 +112,8 @@ int upload_scene(ptx_scene* sc) {
 	d.spaces = (const SpaceRec*)sc->d_spaces.p;
 	d.model_space = (const uint32_t*)sc->d_model_space.p;
 	d.n_spaces = (uint32_t)h.spaces.size();
+	d.n_key = (uint32_t)h.key_surfaces.size();
+	for (uint32_t k = 0; k < 8; k++) d.key_surf[k] = k < d.n_key ? h.key_surfaces[k] : 0u;
 	d.n_surfaces = (uint32_t)h.surfaces.size();
 	d.any_alpha = h.any_alpha ? 1u : 0u;
 	d.n_models = (int32_t)h.models.size();

@@ -276,6 +276,13 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 			v.kd_root = s.surfaces[si].kd_root;
 			v.model_space = (uint32_t)mi | (s.model_space[mi] << 24);
 		}
+	{   // sort key: the surfaces a ray is most expensive to meet (leaf references ~ triangle tests + tree size)
+		std::vector<uint32_t> order(n_surf);
+		for (size_t i = 0; i < n_surf; i++) order[i] = (uint32_t)i;
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return s.surf_range[8 * a + 7] + s.surf_range[8 * a + 5] > s.surf_range[8 * b + 7] + s.surf_range[8 * b + 5]; });
+		order.resize(std::min<size_t>(order.size(), 8));
+		s.key_surfaces = order;
+	}
 	s.shade.assign(n_surf, ShadeRec{});
 	for (size_t mi = 0; mi < n_models; mi++)
 		for (int32_t k = 0; k < s.models[mi].n_surfaces; k++) {
