@@ -65,6 +65,17 @@ struct Geom {
 	const float4* tris;
 };
 
+// The small per-model / per-surface tables are read with a wave-uniform index. They are passed to the kernels as
+// separate `const T* __restrict__` arguments (not inside DevScene): only then can the compiler prove that the
+// kernel's own stores do not clobber them and fetch them with scalar loads (s_load -> SGPRs) instead of one
+// vector load per field per lane.
+struct Tables {
+	const ModelRec* models;
+	const SurfaceRec* surfaces;
+	const SpaceRec* spaces;
+	const uint32_t* model_space;
+};
+
 // geometry::aabb::intersect — geometry/aabb.cpp:41-67
 DEV bool aabb_test(const float* mn, const float* mx, V3 o, V3 d, float& nr, float& fr) {
 	if (mn[0] > mx[0] || mn[1] > mx[1] || mn[2] > mx[2]) return false;
@@ -649,7 +660,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 //   EXTEND: (generate or) load ray -> closest hit -> 16-byte hit record        (traversal state only in registers)
 //   SHADE : load ray + hit + path state -> BSDF, radiance, next ray -> compacted write (path state only)
 template <bool LDS, bool SUN, bool ALPHA, int NSPACE>
-__global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S, RenderParams P, PassBuffers B) {
+__global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParams P, PassBuffers B, const ModelRec* __restrict__ t_models, const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
+	DevScene S = S0;
+	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;  // see struct Tables
 	const Staged st = stage_geometry<LDS>(S, g_smem);
 	const Geom g = st.g;
 	const uint32_t lane = threadIdx.x & 63u;
@@ -813,7 +826,9 @@ DEV void entry_store(float4* q, uint32_t pos, V3 dw, uint32_t id, V3 T, V3 L, co
 constexpr uint32_t kRefillMin = 12;  // refill when at least this many lanes are idle (or nothing else is runnable)
 
 template <bool LDS, int NSPACE>
-__global__ void __launch_bounds__(kBlock) k_render_pass_coop(DevScene S, RenderParams P, PassBuffers B) {
+__global__ void __launch_bounds__(kBlock) k_render_pass_coop(DevScene S0, RenderParams P, PassBuffers B, const ModelRec* __restrict__ t_models, const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
+	DevScene S = S0;
+	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;  // see struct Tables
 	const Staged stg = stage_geometry<LDS>(S, g_smem);
 	const Geom g = stg.g;
 	const ShadeRec* shade = stg.shade;
@@ -1104,7 +1119,9 @@ DEV void scene_traverse_masked(const DevScene& S, const Geom& g, const V3* lo, c
 }
 
 template <bool LDS, int NSPACE>
-__global__ void __launch_bounds__(kBlock) k_render_pass_sorted(DevScene S, RenderParams P, PassBuffers B, uint32_t bins_offset) {
+__global__ void __launch_bounds__(kBlock) k_render_pass_sorted(DevScene S0, RenderParams P, PassBuffers B, uint32_t bins_offset, const ModelRec* __restrict__ t_models, const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
+	DevScene S = S0;
+	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;  // see struct Tables
 	const Staged stg = stage_geometry<LDS>(S, g_smem);
 	const Geom g = stg.g;
 	const ShadeRec* shade = stg.shade;
@@ -1151,6 +1168,9 @@ __global__ void __launch_bounds__(kBlock) k_render_pass_sorted(DevScene S, Rende
 			const bool last = depth + 1 == P.bounces;
 			rays += n_in;
 
+#ifdef PTX_STAMP
+			const unsigned long long t_0 = __builtin_amdgcn_s_memtime();
+#endif
 			// ---------------- SORT: counting sort of the chunk by the surface-mask key
 			for (uint32_t k = lane; k < 256u; k += 64u) bins[k] = 0u;
 			for (uint32_t base = 0; base < n_in; base += 64) {
@@ -1181,6 +1201,9 @@ __global__ void __launch_bounds__(kBlock) k_render_pass_sorted(DevScene S, Rende
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
+#ifdef PTX_STAMP
+			const unsigned long long t_1 = __builtin_amdgcn_s_memtime();
+#endif
 			// ---------------- EXTEND in sorted order
 			for (uint32_t base = 0; base < n_in; base += 64) {
 				const uint32_t pos = base + lane;
@@ -1202,6 +1225,9 @@ __global__ void __launch_bounds__(kBlock) k_render_pass_sorted(DevScene S, Rende
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
+#ifdef PTX_STAMP
+			const unsigned long long t_2 = __builtin_amdgcn_s_memtime();
+#endif
 			// ---------------- SHADE + wave-level stream compaction (+ setup of the next ray)
 			uint32_t n_out = 0;
 			for (uint32_t base = 0; base < n_in; base += 64) {
@@ -1235,6 +1261,10 @@ __global__ void __launch_bounds__(kBlock) k_render_pass_sorted(DevScene S, Rende
 			n_in = n_out;
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef PTX_STAMP
+			const unsigned long long t_3 = __builtin_amdgcn_s_memtime();
+			if (lane == 0) { atomicAdd(g_diag + 0, t_1 - t_0); atomicAdd(g_diag + 1, t_2 - t_1); atomicAdd(g_diag + 2, t_3 - t_2); }
+#endif
 		}
 	}
 	if (lane == 0 && rays) atomicAdd(B.ray_counter, (unsigned long long)rays);
@@ -1254,7 +1284,9 @@ __global__ void k_resolve(const float4* __restrict__ sample_rad, float4* __restr
 
 // ------------------------------------------------------------------------------------ batch intersect
 template <bool LDS, int NSPACE>
-__global__ void __launch_bounds__(kBlock) k_intersect_batch(DevScene S, IntersectArgs A) {
+__global__ void __launch_bounds__(kBlock) k_intersect_batch(DevScene S0, IntersectArgs A, const ModelRec* __restrict__ t_models, const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
+	DevScene S = S0;
+	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;  // see struct Tables
 	const Staged st = stage_geometry<LDS>(S, g_smem);
 	const Geom g = st.g;
 	const Spill spill{A.spill + (size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * (kSpillStack * 64) + (threadIdx.x & 63u)};
@@ -1320,7 +1352,7 @@ static hipError_t launch_pass_variant(const DevScene& S, const RenderParams& P, 
 		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<LDS, SUN, ALPHA, NSPACE>), lds_bytes);
 		if (e != hipSuccess) return e;
 	}
-	hipLaunchKernelGGL((k_render_pass<LDS, SUN, ALPHA, NSPACE>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B);
+	hipLaunchKernelGGL((k_render_pass<LDS, SUN, ALPHA, NSPACE>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B, S.models, S.surfaces, S.spaces, S.model_space);
 	return hipGetLastError();
 }
 template <bool LDS, int NSPACE>
@@ -1329,7 +1361,7 @@ static hipError_t launch_coop(const DevScene& S, const RenderParams& P, const Pa
 		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass_coop<LDS, NSPACE>), lds_bytes);
 		if (e != hipSuccess) return e;
 	}
-	hipLaunchKernelGGL((k_render_pass_coop<LDS, NSPACE>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B);
+	hipLaunchKernelGGL((k_render_pass_coop<LDS, NSPACE>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B, S.models, S.surfaces, S.spaces, S.model_space);
 	return hipGetLastError();
 }
 template <bool LDS, int NSPACE>
@@ -1337,16 +1369,17 @@ static hipError_t launch_sorted(const DevScene& S, const RenderParams& P, const 
 	const size_t geo = LDS ? lds_bytes : 0, total = geo + (size_t)(kBlock / 64) * 256 * 4;
 	hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass_sorted<LDS, NSPACE>), total);
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL((k_render_pass_sorted<LDS, NSPACE>), dim3(grid), dim3(kBlock), total, stream, S, P, B, (uint32_t)geo);
+	hipLaunchKernelGGL((k_render_pass_sorted<LDS, NSPACE>), dim3(grid), dim3(kBlock), total, stream, S, P, B, (uint32_t)geo, S.models, S.surfaces, S.spaces, S.model_space);
 	return hipGetLastError();
 }
 template <bool LDS, bool SUN, bool ALPHA>
 static hipError_t launch_pass_space(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
 	// wave-cooperative traversal needs the surface mask in 64 bits and the local rays of all spaces in registers
-	// Schedules of the same arithmetic (bit-identical results): "sorted" (default where it applies), "coop"
-	// (PTX_COOP=1: wave-cooperative state machine, experimental), per-lane (PTX_SIMPLE=1, and every scene the others do not cover).
-	static const bool want_coop = getenv("PTX_COOP") != nullptr, want_simple = getenv("PTX_SIMPLE") != nullptr;
-	const bool fast = !want_simple && S.n_surfaces <= (uint32_t)kMaxFastSurfaces && S.n_spaces <= (uint32_t)kMaxFastSpaces;
+	// Schedules of the same arithmetic (bit-identical results): per-lane traversal (default: fastest today), and two
+	// experimental ones kept for comparison: PTX_SORTED=1 (chunk counting-sorted by surface mask) and PTX_COOP=1
+	// (wave-cooperative state machine with lane refill).
+	static const bool want_coop = getenv("PTX_COOP") != nullptr, want_sorted = getenv("PTX_SORTED") != nullptr;
+	const bool fast = (want_coop || want_sorted) && S.n_surfaces <= (uint32_t)kMaxFastSurfaces && S.n_spaces <= (uint32_t)kMaxFastSpaces;
 	if constexpr (!SUN && !ALPHA) {
 		if (fast && want_coop) {
 			if (S.n_spaces <= 1) return launch_coop<LDS, 1>(S, P, B, lds_bytes, grid, stream);
@@ -1380,6 +1413,7 @@ hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const Pa
 void diag_dump() {
 	unsigned long long h[8];
 	if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof h) != hipSuccess) return;
+	fprintf(stderr, "[PTX_STAMP] sorted kernel wave-cycles: sort %.3g  extend %.3g  shade %.3g\n", (double)h[0], (double)h[1], (double)h[2]);
 	const double per64 = h[4] / 64.0;
 	fprintf(stderr, "[PTX_STAMP] rays=%llu  per 64 rays: tri trips %.2f (%.1f lanes), adv trips %.2f (%.1f lanes), refill trips %.2f (%.1f lanes), node-loop iters %.2f\n", h[4],
 	        h[0] / per64, (double)h[2] / (h[0] ? h[0] : 1), h[1] / per64, (double)h[3] / (h[1] ? h[1] : 1), h[5] / per64, (double)h[6] / (h[5] ? h[5] : 1), h[7] / per64);
@@ -1395,7 +1429,7 @@ static hipError_t launch_intersect_variant(const DevScene& S, const IntersectArg
 		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_intersect_batch<LDS, NSPACE>), lds_bytes);
 		if (e != hipSuccess) return e;
 	}
-	hipLaunchKernelGGL((k_intersect_batch<LDS, NSPACE>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, A);
+	hipLaunchKernelGGL((k_intersect_batch<LDS, NSPACE>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, A, S.models, S.surfaces, S.spaces, S.model_space);
 	return hipGetLastError();
 }
 hipError_t launch_intersect(const DevScene& S, const IntersectArgs& A, bool lds, size_t lds_bytes, int grid, hipStream_t stream) {
