@@ -31,6 +31,12 @@ inline KdNode kd_make_leaf(uint32_t first_ref, uint32_t count) { return {first_r
 // xyz = corner position (mesh-local space), w = bit pattern of the GLOBAL vertex id of that corner
 struct TriRec { float ax, ay, az; uint32_t ia; float bx, by, bz; uint32_t ib; float cx, cy, cz; uint32_t ic; };
 
+// ---- triangle intersection record: 3 x float4 (48 B), the form the traversal kernels stage through LDS:
+// a.xyz, c3 | e1 = a-b | e2 = a-c, with c3 = e1.y*e2.z - e2.y*e1.z — the ray-independent sub-terms of the
+// reference's Cramer solve (triangle.cpp:136-147: m.x = a-b, m.y = a-c, c3), computed once on the host with
+// the same float operations (so the same bits) instead of once per ray-triangle test.
+struct TriIsect { float ax, ay, az, c3; float e1x, e1y, e1z, p0; float e2x, e2y, e2z, p1; };
+
 // ---- vertex attributes: 2 x float4 (32 B) — normal.xyz, u | tangent.xyz, v ----
 struct VertAttr { float nx, ny, nz, u, tx, ty, tz, v; };
 
@@ -112,7 +118,8 @@ struct FlatScene {
 	std::vector<uint32_t> key_surfaces;  // up to 8 surfaces with the most leaf references (sort key of the sorted kernel)
 	std::vector<KdNode> kd_nodes;
 	std::vector<uint32_t> kd_refs;       // global triangle ids
-	std::vector<TriRec> tris;
+	std::vector<TriRec> tris;            // corners + vertex ids (shading: attribute interpolation)
+	std::vector<TriIsect> tri_isect;     // intersection form (traversal)
 	std::vector<VertAttr> vattr;
 	CameraRec camera{};
 	SunRec sun{};

@@ -62,7 +62,7 @@ DEV V3 mulmv(const float* m, V3 v) {
 struct Geom {
 	const uint2* nodes;
 	const uint32_t* refs;
-	const float4* tris;
+	const float4* tris;   // TriIsect records: (a, c3) (e1) (e2)
 };
 
 // The small per-model / per-surface tables are read with a wave-uniform index. They are passed to the kernels as
@@ -107,6 +107,23 @@ DEV float tri_test(V3 a, V3 b, V3 c, V3 o, V3 d, float& alpha, float& beta, floa
 	return dist;
 }
 
+// The same solve from a TriIsect record: e1 = a-b, e2 = a-c and c3 come precomputed (identical float operations).
+DEV float tri_test_pre(float4 A, float4 E1, float4 E2, V3 o, V3 d, float& beta, float& gamma) {
+	const V3 v = mk(A.x - o.x, A.y - o.y, A.z - o.z);
+	const float c1 = E2.y * d.z - d.y * E2.z;
+	const float c2 = E1.y * d.z - d.y * E1.z;
+	const float c3 = A.w;
+	const float c4 = v.y * d.z - d.y * v.z;
+	const float c5 = E1.y * v.z - v.y * E1.z;
+	const float c6 = E2.y * v.z - v.y * E2.z;
+	const float inv_det = 1.0f / (E1.x * c1 - E2.x * c2 + d.x * c3);
+	beta = inv_det * (v.x * c1 - E2.x * c4 - d.x * c6);
+	if (beta < 0 - kEps || beta > 1 + kEps) return -1.0f;
+	gamma = inv_det * (E1.x * c4 - v.x * c2 + d.x * c5);
+	if (gamma < 0 - kEps || gamma + beta > 1 + kEps) return -1.0f;
+	return inv_det * (E1.x * c6 - E2.x * c5 + v.x * c3);
+}
+
 struct MeshHit { float t; float b1, b2; uint32_t tri; };
 
 constexpr int kRegStack = 3;    // pending KD subtrees kept in registers (covers > 99 % of traversals)
@@ -123,12 +140,23 @@ DEV void spill_get(const Spill& sp, int k, uint32_t& node, float& m) { uint2 v =
 
 // geometry::aabb::intersect with the reciprocal direction hoisted: the same local ray is tested against the
 // model box and every surface box, and 1/dir has one value per ray whatever box it meets.
+// The reference's min/max are compare-selects whose result depends on operand order when a NaN is involved
+// (math.inl:169-182); NaNs appear here only as 0 * inf (origin exactly on a box plane, direction exactly parallel
+// to it). Without a NaN, hardware v_min/v_max give the same values (up to the sign of a zero, which no later
+// comparison distinguishes), so: fast path on v_min_f32 / v_max3_f32, exact compare-select path when the sum of
+// the six slab distances is NaN (which also catches inf - inf; taking the exact path then is merely slower).
 DEV bool aabb_test_inv(const float* mn, const float* mx, V3 o, V3 inv, float& nr, float& fr) {
 	if (mn[0] > mx[0] || mn[1] > mx[1] || mn[2] > mx[2]) return false;
-	float ax = (mn[0] - o.x) * inv.x, ay = (mn[1] - o.y) * inv.y, az = (mn[2] - o.z) * inv.z;
-	float bx = (mx[0] - o.x) * inv.x, by = (mx[1] - o.y) * inv.y, bz = (mx[2] - o.z) * inv.z;
-	nr = pmax(pmax(pmin(ax, bx), pmin(ay, by)), pmin(az, bz));
-	fr = pmin(pmin(pmax(ax, bx), pmax(ay, by)), pmax(az, bz));
+	const float ax = (mn[0] - o.x) * inv.x, ay = (mn[1] - o.y) * inv.y, az = (mn[2] - o.z) * inv.z;
+	const float bx = (mx[0] - o.x) * inv.x, by = (mx[1] - o.y) * inv.y, bz = (mx[2] - o.z) * inv.z;
+	const float s = ((ax + bx) + (ay + by)) + (az + bz);
+	if (s == s) {
+		nr = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+		fr = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+	} else {
+		nr = pmax(pmax(pmin(ax, bx), pmin(ay, by)), pmin(az, bz));
+		fr = pmin(pmin(pmax(ax, bx), pmax(ay, by)), pmax(az, bz));
+	}
 	if (nr > fr) return false;
 	return fr >= 0;
 }
@@ -193,9 +221,9 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, 
 		uint32_t best_tri = 0;
 		for (uint32_t i = 0; i < count; i++) {
 			uint32_t ti = g.refs[first_ref + i];
-			float4 A = g.tris[3 * ti], B = g.tris[3 * ti + 1], C = g.tris[3 * ti + 2];
-			float al, be, ga;
-			float t = tri_test(mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), mk(C.x, C.y, C.z), o, d, al, be, ga);
+			const float4 A = g.tris[3 * ti], E1 = g.tris[3 * ti + 1], E2 = g.tris[3 * ti + 2];
+			float be, ga;
+			const float t = tri_test_pre(A, E1, E2, o, d, be, ga);
 			if (t >= 0 && t <= max_dist && (t < best_t || !(best_t >= 0))) { best_t = t; bb1 = be; bb2 = ga; best_tri = ti; }
 		}
 		if (!(best_t >= 0)) continue;
@@ -212,12 +240,20 @@ struct SceneHit { float dist; int surface; uint32_t tri; float b1, b2; };
 DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& best, const Spill& spill) {
 	best.dist = -1.0f;
 	best.surface = -1;
+	uint32_t cur_space = 0xFFFFFFFFu;
+	V3 lo = o, ld = d, inv = d;
 	for (int m = 0; m < S.n_models; m++) {
 		const ModelRec& M = S.models[m];
-		// ray::transform(inverse): origin' = inv*o, dir' = normalize(inv.basis*dir)  (geometry/ray.cpp:10-15)
-		V3 lo = mulmv(M.inv_basis, o) + mk(M.inv_origin[0], M.inv_origin[1], M.inv_origin[2]);
-		V3 ld = normalize(mulmv(M.inv_basis, d));
-		V3 inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+		// ray::transform(inverse): origin' = inv*o, dir' = normalize(inv.basis*dir)  (geometry/ray.cpp:10-15); models whose
+		// transforms are bitwise equal share a SpaceRec, so the local ray is recomputed only when the space changes
+		const uint32_t spc = S.model_space[m];   // wave-uniform
+		if (spc != cur_space) {
+			const SpaceRec& SP = S.spaces[spc];
+			lo = mulmv(SP.inv_basis, o) + mk(SP.inv_origin[0], SP.inv_origin[1], SP.inv_origin[2]);
+			ld = normalize(mulmv(SP.inv_basis, d));
+			inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+			cur_space = spc;
+		}
 		float nr, fr;
 		if (!aabb_test_inv(M.bmin, M.bmax, lo, inv, nr, fr)) continue;
 		MeshHit nearest;
@@ -309,9 +345,9 @@ DEV void extend64(const DevScene& S, const Geom& g, const ShadeRec* shade, const
 			// ---------------- TRI: one leaf triangle (mesh.cpp:381-389; ties keep the first)
 			if (want_tri) {
 				const uint32_t ti = g.refs[rcur];
-				const float4 A = g.tris[3 * ti], B = g.tris[3 * ti + 1], C = g.tris[3 * ti + 2];
-				float al, be, ga;
-				const float t = tri_test(mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), mk(C.x, C.y, C.z), co, cd, al, be, ga);
+				const float4 A = g.tris[3 * ti], E1 = g.tris[3 * ti + 1], E2 = g.tris[3 * ti + 2];
+				float be, ga;
+				const float t = tri_test_pre(A, E1, E2, co, cd, be, ga);
 				if (t >= 0 && t <= tmax && (t < lt || !(lt >= 0))) { lt = t; lb1 = be; lb2 = ga; ltri = ti; }
 				rcur++;
 			}
@@ -411,7 +447,7 @@ struct Surf { V3 pos, nrm, tan; float u, v; };
 // attribute interpolation of renderer::intersect — core/renderer.cpp:688-715
 DEV void hit_attributes(const DevScene& S, const Geom& g, const ShadeRec& R, uint32_t tri, float b1, float b2, Surf& out) {
 	const float b0 = 1 - b1 - b2;
-	float4 A = g.tris[3 * tri], B = g.tris[3 * tri + 1], C = g.tris[3 * tri + 2];
+	const float4 A = S.tris[3 * tri], B = S.tris[3 * tri + 1], C = S.tris[3 * tri + 2];   // TriRec (global: once per hit)
 	uint32_t ia = __float_as_uint(A.w), ib = __float_as_uint(B.w), ic = __float_as_uint(C.w);
 	float4 a0 = S.vattr[2 * ia], a1 = S.vattr[2 * ia + 1];
 	float4 c0 = S.vattr[2 * ic], c1 = S.vattr[2 * ic + 1];
@@ -627,12 +663,12 @@ struct Staged { Geom g; const ShadeRec* shade; const VisitRec* visits; };
 
 template <bool LDS>
 DEV Staged stage_geometry(const DevScene& S, unsigned char* smem) {
-	if constexpr (!LDS) return {{S.nodes, S.refs, S.tris}, S.shade, S.visits};
+	if constexpr (!LDS) return {{S.nodes, S.refs, S.tri_isect}, S.shade, S.visits};
 	else {
 		// [triangle records][shade records][visit records][KD nodes][leaf refs], each region a multiple of 16 B
 		uint4* dst = reinterpret_cast<uint4*>(smem);
 		const uint32_t n_tri16 = S.n_tris * 3, n_shade16 = S.n_surfaces * 9, n_visit16 = S.n_surfaces * 2, n_node16 = (S.n_nodes + 1) / 2, n_ref16 = (S.n_refs + 3) / 4;
-		const uint4* src_t = reinterpret_cast<const uint4*>(S.tris);
+		const uint4* src_t = reinterpret_cast<const uint4*>(S.tri_isect);
 		const uint4* src_s = reinterpret_cast<const uint4*>(S.shade);
 		const uint4* src_v = reinterpret_cast<const uint4*>(S.visits);
 		const uint4* src_n = reinterpret_cast<const uint4*>(S.nodes);
@@ -932,9 +968,9 @@ __global__ void __launch_bounds__(kBlock) k_render_pass_coop(DevScene S0, Render
 						// ---------------- TRI: one leaf triangle (mesh.cpp:381-389; ties keep the first)
 						if (want_tri) {
 							const uint32_t ti = g.refs[rcur];
-							const float4 A = g.tris[3 * ti], Bv = g.tris[3 * ti + 1], C = g.tris[3 * ti + 2];
-							float al, be, ga;
-							const float t = tri_test(mk(A.x, A.y, A.z), mk(Bv.x, Bv.y, Bv.z), mk(C.x, C.y, C.z), co, cd, al, be, ga);
+							const float4 A = g.tris[3 * ti], E1 = g.tris[3 * ti + 1], E2 = g.tris[3 * ti + 2];
+							float be, ga;
+							const float t = tri_test_pre(A, E1, E2, co, cd, be, ga);
 							if (t >= 0 && t <= tmax && (t < lt || !(lt >= 0))) { lt = t; lb1 = be; lb2 = ga; ltri = ti; }
 							rcur++;
 						}

@@ -23,7 +23,8 @@ struct DevScene {
 	const MaterialRec* materials;
 	const uint2* nodes;
 	const uint32_t* refs;
-	const float4* tris;   // 3 per triangle
+	const float4* tris;   // 3 per triangle: corners + vertex ids (TriRec)
+	const float4* tri_isect; // 3 per triangle: intersection form (TriIsect)
 	const float4* vattr;  // 2 per vertex
 	const ShadeRec* shade; // 1 per surface
 	const VisitRec* visits; // 1 per surface, visit order

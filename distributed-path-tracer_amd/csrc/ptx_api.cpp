@@ -66,7 +66,7 @@ struct ptx_ctx {
 struct ptx_scene {
 	ptx_ctx* ctx = nullptr;
 	FlatScene host;
-	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr, d_shade, d_visits, d_spaces, d_model_space;
+	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr, d_isect, d_shade, d_visits, d_spaces, d_model_space;
 	DevScene dev{};
 	bool lds = false;
 	size_t lds_bytes = 0;
@@ -93,6 +93,7 @@ int upload_scene(ptx_scene* sc) {
 	HIP_TRY(up(sc->d_nodes, h.kd_nodes.data(), h.kd_nodes.size() * 8, pad16(h.kd_nodes.size() * 8)));
 	HIP_TRY(up(sc->d_refs, h.kd_refs.data(), h.kd_refs.size() * 4, pad16(h.kd_refs.size() * 4)));
 	HIP_TRY(up(sc->d_tris, h.tris.data(), h.tris.size() * 48, h.tris.size() * 48));
+	HIP_TRY(up(sc->d_isect, h.tri_isect.data(), h.tri_isect.size() * 48, h.tri_isect.size() * 48));
 	HIP_TRY(up(sc->d_vattr, h.vattr.data(), h.vattr.size() * 32, h.vattr.size() * 32));
 	HIP_TRY(up(sc->d_shade, h.shade.data(), h.shade.size() * sizeof(ShadeRec), h.shade.size() * sizeof(ShadeRec)));
 	HIP_TRY(up(sc->d_visits, h.visits.data(), h.visits.size() * sizeof(VisitRec), h.visits.size() * sizeof(VisitRec)));
@@ -107,6 +108,7 @@ int upload_scene(ptx_scene* sc) {
 	d.refs = (const uint32_t*)sc->d_refs.p;
 	d.tris = (const float4*)sc->d_tris.p;
 	d.vattr = (const float4*)sc->d_vattr.p;
+	d.tri_isect = (const float4*)sc->d_isect.p;
 	d.shade = (const ShadeRec*)sc->d_shade.p;
 	d.visits = (const VisitRec*)sc->d_visits.p;
 	d.spaces = (const SpaceRec*)sc->d_spaces.p;
@@ -255,7 +257,7 @@ void ptx_scene_destroy(ptx_scene* sc) {
 		(void)hipSetDevice(sc->ctx->device);
 		(void)hipStreamSynchronize(sc->ctx->stream);
 		sc->d_models.release(); sc->d_surfaces.release(); sc->d_materials.release(); sc->d_nodes.release();
-		sc->d_refs.release(); sc->d_tris.release(); sc->d_vattr.release(); sc->d_shade.release(); sc->d_visits.release(); sc->d_spaces.release(); sc->d_model_space.release();
+		sc->d_refs.release(); sc->d_tris.release(); sc->d_vattr.release(); sc->d_isect.release(); sc->d_shade.release(); sc->d_visits.release(); sc->d_spaces.release(); sc->d_model_space.release();
 	}
 	delete sc;
 }

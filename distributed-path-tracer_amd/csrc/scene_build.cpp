@@ -152,7 +152,7 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 	s.models.assign(n_models, ModelRec{});
 	s.surfaces.assign(n_surf, SurfaceRec{});
 	s.materials.assign(n_surf, MaterialRec{});
-	s.kd_nodes.clear(); s.kd_refs.clear(); s.tris.clear(); s.vattr.clear();
+	s.kd_nodes.clear(); s.kd_refs.clear(); s.tris.clear(); s.tri_isect.clear(); s.vattr.clear();
 	s.kd_max_depth = 0;
 	s.any_texture = false;
 	s.any_alpha = false;
@@ -186,6 +186,8 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 			memcpy(pa[t].v, a, 12); memcpy(pb[t].v, b, 12); memcpy(pc[t].v, c, 12);
 			s.tris.push_back({a[0], a[1], a[2], (uint32_t)(v0 + ix[0]), b[0], b[1], b[2], (uint32_t)(v0 + ix[1]),
 			                  c[0], c[1], c[2], (uint32_t)(v0 + ix[2])});
+			const float e1[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]}, e2[3] = {a[0] - c[0], a[1] - c[1], a[2] - c[2]};
+			s.tri_isect.push_back({a[0], a[1], a[2], e1[1] * e2[2] - e2[1] * e1[2], e1[0], e1[1], e1[2], 0.f, e2[0], e2[1], e2[2], 0.f});
 		}
 		MeshBuilder mbuild{pa, pb, pc, {}, 0};
 		std::vector<uint32_t> all(nt);
