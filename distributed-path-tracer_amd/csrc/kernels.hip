@@ -442,6 +442,36 @@ DEV void extend64(const DevScene& S, const Geom& g, const ShadeRec* shade, const
 #endif
 }
 
+// ------------------------------------------------------------------------------------ deferred models
+// scene_traverse makes the whole wave wait for every model that ANY of its 64 rays enters: on Cornell 9 % / 4 % / 3 % /
+// 1.5 % of the rays enter the two boxes, the light and the sphere, so their triangle loops run with a handful of
+// lanes in almost every wave-iteration. Here a model entered by fewer than kInlineMin lanes of a wave-iteration is
+// not traversed on the spot: the lanes append their ray index to that model's wave-private list, and after the sweep
+// each list is traversed with full waves. Per ray the arithmetic is unchanged; the closest hit is the minimum over
+// models of the world distance, ties going to the model visited first (renderer.cpp:663-669), which is evaluated
+// here as (distance, surface id) order because surface ids grow with the visit order.
+constexpr uint32_t kInlineMin = 16;        // lanes of a wave-iteration that make a model worth traversing on the spot
+constexpr uint32_t kListCap = 16u * (kInlineMin - 1u) + 16u;   // entries a list can receive per chunk (kChunk / 64 iterations)
+constexpr int kMaxDeferModels = 64;        // per-model list lengths live in the lanes of one VGPR
+
+// Closest hit inside ONE model for a lane that is known to enter its box: scene::model::intersect (model.cpp:27-63)
+DEV bool model_traverse(const DevScene& S, const Geom& g, const ModelRec& M, V3 lo, V3 ld, V3 inv, float& wd, int& surf, uint32_t& tri,
+                        float& b1, float& b2, const Spill& spill) {
+	MeshHit nearest;
+	nearest.t = -1.0f;
+	int hit_surface = -1;
+	for (int k = 0; k < M.n_surfaces; k++) {
+		MeshHit h;
+		if (!mesh_traverse(g, S.surfaces[M.first_surface + k], lo, ld, inv, h, spill)) continue;
+		if (h.t < nearest.t || !(nearest.t >= 0)) { nearest = h; hit_surface = M.first_surface + k; }
+	}
+	if (!(nearest.t >= 0)) return false;
+	wd = length(mulmv(M.basis, ld * nearest.t));
+	if (!(wd >= 0)) return false;
+	surf = hit_surface; tri = nearest.tri; b1 = nearest.b1; b2 = nearest.b2;
+	return true;
+}
+
 struct Surf { V3 pos, nrm, tan; float u, v; };
 
 // attribute interpolation of renderer::intersect — core/renderer.cpp:688-715
@@ -706,6 +736,8 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 	// wave-private streams: 2 ray buffers x 4 float4 arrays x kChunk entries, then 1 hit array
 	float4* qbase = B.queues + (size_t)wave_slot * (kQueueFloat4PerWave);
 	float4* hbuf = qbase + 2u * 4u * kChunk;
+	float* hdist = reinterpret_cast<float*>(hbuf + kChunk);                 // [kChunk] world distance of the current best hit (deferral)
+	uint32_t* lists = reinterpret_cast<uint32_t*>(hbuf + kChunk) + kChunk;   // [n_models][kListCap] deferred ray indices
 	const Spill spill{B.spill + (size_t)wave_slot * (kSpillStack * 64) + lane};
 	uint32_t rays = 0;
 
@@ -726,6 +758,8 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 			const unsigned long long t_a = __builtin_amdgcn_s_memtime();
 #endif
 			// ---------------- EXTEND
+			const bool defer = NSPACE == 0 && S.n_models <= kMaxDeferModels && S.n_models > 1;
+			uint32_t list_len = 0;   // lane m: entries in model m's deferred list
 			for (uint32_t base = 0; base < n_in; base += 64) {
 				const uint32_t i = base + lane;
 				const bool active = i < n_in;
@@ -746,8 +780,76 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 				}
 				SceneHit h;
 				if constexpr (NSPACE > 0) extend64<NSPACE>(S, g, st.shade, st.visits, o, d, active, h, spill);
-				else if (active) scene_traverse(S, g, o, d, h, spill);
-				if (active) hbuf[i] = make_float4(__int_as_float(h.surface), __uint_as_float(h.tri), h.b1, h.b2);
+				else if (!defer) { if (active) scene_traverse(S, g, o, d, h, spill); }
+				else {
+					// renderer::intersect's model loop with the rarely entered models set aside
+					h.dist = -1.0f; h.surface = -1; h.tri = 0; h.b1 = 0; h.b2 = 0;
+					uint32_t cur_space = 0xFFFFFFFFu;
+					V3 lo = o, ld = d, inv = d;
+					for (int m = 0; m < S.n_models; m++) {
+						const ModelRec& M = S.models[m];
+						const uint32_t spc = S.model_space[m];
+						if (spc != cur_space) {
+							const SpaceRec& SP = S.spaces[spc];
+							lo = mulmv(SP.inv_basis, o) + mk(SP.inv_origin[0], SP.inv_origin[1], SP.inv_origin[2]);
+							ld = normalize(mulmv(SP.inv_basis, d));
+							inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+							cur_space = spc;
+						}
+						float nr, fr;
+						const bool enters = active && aabb_test_inv(M.bmin, M.bmax, lo, inv, nr, fr);
+						const uint64_t em = __ballot(enters);
+						if (em == 0) continue;
+						const uint32_t cnt = (uint32_t)__popcll(em);
+						if (cnt >= kInlineMin) {
+							if (enters) {
+								float wd, b1, b2; int surf; uint32_t tri;
+								if (model_traverse(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill) &&
+								    (wd < h.dist || !(h.dist >= 0) || (wd == h.dist && surf < h.surface))) { h.dist = wd; h.surface = surf; h.tri = tri; h.b1 = b1; h.b2 = b2; }
+							}
+						} else {
+							const uint32_t len = __builtin_amdgcn_readlane(list_len, m);
+							if (enters) {
+								const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+								lists[(uint32_t)m * kListCap + len + r] = i;
+							}
+							list_len = (int)lane == m ? len + cnt : list_len;
+						}
+					}
+				}
+				if (active) { hbuf[i] = make_float4(__int_as_float(h.surface), __uint_as_float(h.tri), h.b1, h.b2); if (defer) hdist[i] = h.dist; }
+			}
+			if (defer) {
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				// the lists, model by model, with full waves
+				for (int m = 0; m < S.n_models; m++) {
+					const uint32_t len = __builtin_amdgcn_readlane(list_len, m);
+					if (len == 0) continue;
+					const ModelRec& M = S.models[m];
+					const SpaceRec& SP = S.spaces[S.model_space[m]];
+					for (uint32_t base = 0; base < len; base += 64) {
+						if (base + lane < len) {
+							const uint32_t i = lists[(uint32_t)m * kListCap + base + lane];
+							const float4 q0 = qin[i], q1 = qin[kChunk + i];
+							const V3 o = mk(q0.x, q0.y, q0.z), d = mk(q1.x, q1.y, q1.z);
+							const V3 lo = mulmv(SP.inv_basis, o) + mk(SP.inv_origin[0], SP.inv_origin[1], SP.inv_origin[2]);
+							const V3 ld = normalize(mulmv(SP.inv_basis, d));
+							const V3 inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+							float wd, b1, b2; int surf; uint32_t tri;
+							if (model_traverse(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill)) {
+								const float bd = hdist[i];
+								const int bs = __float_as_int(hbuf[i].x);
+								if (wd < bd || !(bd >= 0) || (wd == bd && surf < bs)) {
+									hbuf[i] = make_float4(__int_as_float(surf), __uint_as_float(tri), b1, b2);
+									hdist[i] = wd;
+								}
+							}
+						}
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				}
 			}
 			rays += n_in > lane ? (n_in - lane + 63u) / 64u : 0u;  // rays this lane traced in the sweep
 			// the wave re-reads below what other lanes of this wave just wrote
