@@ -450,8 +450,11 @@ DEV void extend64(const DevScene& S, const Geom& g, const ShadeRec* shade, const
 // each list is traversed with full waves. Per ray the arithmetic is unchanged; the closest hit is the minimum over
 // models of the world distance, ties going to the model visited first (renderer.cpp:663-669), which is evaluated
 // here as (distance, surface id) order because surface ids grow with the visit order.
-constexpr uint32_t kInlineMin = 16;        // lanes of a wave-iteration that make a model worth traversing on the spot
-constexpr uint32_t kListCap = 16u * (kInlineMin - 1u) + 16u;   // entries a list can receive per chunk (kChunk / 64 iterations)
+#ifndef PTX_INLINE_MIN
+#define PTX_INLINE_MIN 32
+#endif
+constexpr uint32_t kInlineMin = PTX_INLINE_MIN;        // lanes of a wave-iteration that make a model worth traversing on the spot
+constexpr uint32_t kListCap = (kChunk / 64u) * (kInlineMin - 1u) + 16u;   // entries a list can receive per chunk (kChunk / 64 iterations)
 constexpr int kMaxDeferModels = 64;        // per-model list lengths live in the lanes of one VGPR
 
 // Closest hit inside ONE model for a lane that is known to enter its box: scene::model::intersect (model.cpp:27-63)
@@ -758,7 +761,9 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 			const unsigned long long t_a = __builtin_amdgcn_s_memtime();
 #endif
 			// ---------------- EXTEND
-			const bool defer = NSPACE == 0 && S.n_models <= kMaxDeferModels && S.n_models > 1;
+			// lists live in the unused part of the wave's stream area: hdist (kChunk words) + n_models lists
+			const bool defer = NSPACE == 0 && S.n_models <= kMaxDeferModels && S.n_models > 1 &&
+			                   (uint32_t)S.n_models * kListCap + kChunk <= (kQueueFloat4PerWave - 9u * kChunk) * 4u;
 			uint32_t list_len = 0;   // lane m: entries in model m's deferred list
 			for (uint32_t base = 0; base < n_in; base += 64) {
 				const uint32_t i = base + lane;

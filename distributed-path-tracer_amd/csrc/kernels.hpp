@@ -11,7 +11,10 @@ namespace ptx {
 #define PTX_BLOCK 1024
 #endif
 constexpr int kBlock = PTX_BLOCK;  // threads per workgroup (one workgroup per CU): 1024 = 16 waves = 4 per SIMD
-constexpr uint32_t kChunk = 1024; // camera paths a wave takes per counter fetch (16 wave-iterations)
+#ifndef PTX_CHUNK
+#define PTX_CHUNK 1024
+#endif
+constexpr uint32_t kChunk = PTX_CHUNK; // camera paths a wave takes per counter fetch (16 wave-iterations)
 // wave-private stream space, in float4: two ray buffers of up to 9 arrays + one hit-record array
 constexpr uint32_t kQueueFloat4PerWave = (2u * 9u + 1u) * kChunk;  // cooperative kernel: 3 + 3*2 arrays per buffer
 constexpr uint32_t kSpillWords = 24u * 64u;  // uint2 per wave: kSpillStack levels x 64 lanes
