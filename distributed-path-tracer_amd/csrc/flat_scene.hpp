@@ -86,13 +86,6 @@ struct SpaceRec {
 	float inv_origin[3];
 };
 
-// ---- visit list: one entry per surface in the order renderer::intersect would reach it
-// (models in visit order, surfaces in model order). 32 B = 2 x float4.
-struct VisitRec {
-	float bmin[3]; uint32_t kd_root;
-	float bmax[3]; uint32_t model_space;  // model index | space index << 24
-};
-
 struct CameraRec { float origin[3]; float basis[9]; float fov; float tan_half_fov; };
 struct SunRec { float basis[9]; float energy[3]; float angular_radius; uint32_t present; };
 
@@ -114,8 +107,6 @@ struct FlatScene {
 	std::vector<ShadeRec> shade;         // per surface
 	std::vector<SpaceRec> spaces;        // distinct world->local transforms
 	std::vector<uint32_t> model_space;   // per model
-	std::vector<VisitRec> visits;        // per surface
-	std::vector<uint32_t> key_surfaces;  // up to 8 surfaces with the most leaf references (sort key of the sorted kernel)
 	std::vector<KdNode> kd_nodes;
 	std::vector<uint32_t> kd_refs;       // global triangle ids
 	std::vector<TriRec> tris;            // corners + vertex ids (shading: attribute interpolation)

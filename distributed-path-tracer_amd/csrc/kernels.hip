@@ -275,173 +275,6 @@ DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& 
 	return best.surface >= 0;
 }
 
-// ------------------------------------------------------------------------------------ wave-cooperative closest hit
-// Same arithmetic and the same visiting order PER RAY as scene_traverse above, but scheduled for a
-// 64-lane wave: every lane walks its own ray through its own sequence of (surface, KD node, leaf triangle)
-// steps, and each trip of the loop runs ONE of two code sections for the whole wave —
-//   TRI     : one triangle test for every lane that has a leaf triangle pending  (the bulk of the work)
-//   ADVANCE : one bookkeeping step (finish leaf / pop / next surface / KD branch step) for the others
-// — whichever has more lanes waiting. Lanes are therefore never held up by a model or a subtree they do
-// not touch (the per-model loop costs the sum over models of the slowest lane), and each section runs with
-// at least half of the unfinished lanes.
-// Setup is wave-uniform: the local ray of every ray space (SpaceRec) and one AABB test per model / surface
-// give each lane a bit mask of the surfaces it has to traverse.
-// Must be called from wave-uniform control flow; `active` masks lanes without a ray.
-#ifdef PTX_STAMP
-__device__ unsigned long long g_diag[8];
-#endif
-constexpr uint32_t ST_NEXT = 0, ST_NODE = 1, ST_LEAF = 2, ST_POP = 3, ST_DONE = 4;
-constexpr int kMaxFastSurfaces = 64, kMaxFastSpaces = 2;
-
-template <int NSPACE>
-DEV void extend64(const DevScene& S, const Geom& g, const ShadeRec* shade, const VisitRec* visits, V3 o, V3 d, bool active,
-                  SceneHit& best, const Spill& spill) {
-	// ---- uniform setup: local rays, surface mask
-	V3 lo[NSPACE], ld[NSPACE], inv[NSPACE];
-#pragma unroll
-	for (int k = 0; k < NSPACE; k++) {
-		const SpaceRec& sp = S.spaces[k];
-		lo[k] = mulmv(sp.inv_basis, o) + mk(sp.inv_origin[0], sp.inv_origin[1], sp.inv_origin[2]);
-		ld[k] = normalize(mulmv(sp.inv_basis, d));
-		inv[k] = mk(1.0f / ld[k].x, 1.0f / ld[k].y, 1.0f / ld[k].z);
-	}
-	uint64_t mask = 0;
-	for (int m = 0; m < S.n_models; m++) {
-		const ModelRec& M = S.models[m];
-		const bool s1 = NSPACE > 1 && S.model_space[m] != 0;  // wave-uniform
-		const V3 mo = s1 ? lo[NSPACE - 1] : lo[0], mi = s1 ? inv[NSPACE - 1] : inv[0];
-		float nr, fr;
-		const bool mh = aabb_test_inv(M.bmin, M.bmax, mo, mi, nr, fr);
-		for (int k = 0; k < M.n_surfaces; k++) {
-			const SurfaceRec& sf = S.surfaces[M.first_surface + k];
-			const bool sh = mh && aabb_test_inv(sf.bmin, sf.bmax, mo, mi, nr, fr);
-			mask |= sh ? (1ull << (M.first_surface + k)) : 0ull;
-		}
-	}
-	if (!active) mask = 0;
-
-	// ---- per-lane traversal state
-	best.dist = -1.0f; best.surface = -1; best.tri = 0; best.b1 = 0; best.b2 = 0;
-	uint32_t st = ST_NEXT;
-	int cur_model = -1, cur_surf = -1;
-	V3 co = lo[0], cd = ld[0];                      // local ray of the surface being traversed
-	float nt = -1.0f, nb1 = 0, nb2 = 0; uint32_t ntri = 0; int nsurf = -1;   // nearest within the current model (local t)
-	uint32_t node = 0; float tmin = 0, tmax = 0, tfar = 0; int sp = 0;
-	uint32_t n0 = 0, n1 = 0, n2 = 0; float m0 = 0, m1 = 0, m2 = 0;
-	uint32_t rcur = 0, rend = 0; float lt = -1.0f, lb1 = 0, lb2 = 0; uint32_t ltri = 0;
-
-#ifdef PTX_STAMP
-	uint32_t dg_tri_trips = 0, dg_adv_trips = 0, dg_tri_lanes = 0, dg_adv_lanes = 0;
-#endif
-	for (;;) {
-		const bool want_tri = rcur < rend;
-		const bool want_adv = !want_tri && st != ST_DONE;
-		const uint64_t mt = __ballot(want_tri), ma = __ballot(want_adv);
-		if ((mt | ma) == 0) break;
-#ifdef PTX_STAMP
-		if (__popcll(mt) >= __popcll(ma)) { dg_tri_trips++; dg_tri_lanes += __popcll(mt); } else { dg_adv_trips++; dg_adv_lanes += __popcll(ma); }
-#endif
-		if (__popcll(mt) >= __popcll(ma)) {
-			// ---------------- TRI: one leaf triangle (mesh.cpp:381-389; ties keep the first)
-			if (want_tri) {
-				const uint32_t ti = g.refs[rcur];
-				const float4 A = g.tris[3 * ti], E1 = g.tris[3 * ti + 1], E2 = g.tris[3 * ti + 2];
-				float be, ga;
-				const float t = tri_test_pre(A, E1, E2, co, cd, be, ga);
-				if (t >= 0 && t <= tmax && (t < lt || !(lt >= 0))) { lt = t; lb1 = be; lb2 = ga; ltri = ti; }
-				rcur++;
-			}
-		} else if (want_adv) {
-			// ---------------- ADVANCE
-			if (st == ST_LEAF) {
-				if (lt >= 0) {   // the leaf produced a hit: mesh::intersect returns it (mesh.cpp:397-401)
-					if (lt < nt || !(nt >= 0)) { nt = lt; nb1 = lb1; nb2 = lb2; ntri = ltri; nsurf = cur_surf; }   // model.cpp:45-49
-					st = ST_NEXT;
-				} else st = ST_POP;
-			}
-			if (st == ST_POP) {
-				if (sp == 0) st = ST_NEXT;
-				else {
-					sp--;
-					node = n0; tmin = m0;
-					n0 = n1; m0 = m1; n1 = n2; m1 = m2;
-					if (sp >= kRegStack) spill_get(spill, sp - kRegStack, n2, m2);
-					tmax = sp > 0 ? m0 : tfar;
-					st = ST_NODE;
-				}
-			}
-			if (st == ST_NEXT) {
-				const bool more = mask != 0;
-				const int s = more ? (int)__builtin_ctzll(mask) : 0;
-				uint32_t ms = 0; float4 v0 = make_float4(0, 0, 0, 0), v1 = v0;
-				if (more) { v0 = reinterpret_cast<const float4*>(visits)[2 * s]; v1 = reinterpret_cast<const float4*>(visits)[2 * s + 1]; ms = __float_as_uint(v1.w); }
-				const int model = more ? (int)(ms & 0xFFFFFFu) : -2;
-				if (model != cur_model) {
-					if (nt >= 0) {   // close the model: local -> world distance (model.cpp:62-63), then renderer.cpp:663-669
-						const ShadeRec& R = shade[nsurf];
-						const float wd = length(mulmv(R.basis, cd * nt));
-						if (wd >= 0 && (wd < best.dist || !(best.dist >= 0))) { best.dist = wd; best.surface = nsurf; best.tri = ntri; best.b1 = nb1; best.b2 = nb2; }
-					}
-					nt = -1.0f;
-					cur_model = model;
-				}
-				if (!more) st = ST_DONE;
-				else {
-					mask &= mask - 1;
-					cur_surf = s;
-					const bool s1 = NSPACE > 1 && (ms >> 24) != 0;
-					co = s1 ? lo[NSPACE - 1] : lo[0];
-					cd = s1 ? ld[NSPACE - 1] : ld[0];
-					const V3 ci = s1 ? inv[NSPACE - 1] : inv[0];
-					const float bmn[3] = {v0.x, v0.y, v0.z}, bmx[3] = {v1.x, v1.y, v1.z};
-					float nr, fr;
-					aabb_test_inv(bmn, bmx, co, ci, nr, fr);   // hit is known from the mask; the distances are needed
-					node = __float_as_uint(v0.w); tmin = nr; tmax = fr; tfar = fr; sp = 0;
-					st = ST_NODE;
-				}
-			}
-			if (st == ST_NODE) {
-				const uint2 nd = g.nodes[node];
-				if ((nd.y & 3u) == KD_LEAF) {
-					rcur = nd.x; rend = nd.x + (nd.y >> 2);
-					lt = -1.0f;
-					st = ST_LEAF;
-				} else {   // one branch step (mesh.cpp:333-369)
-					const uint32_t axis = nd.y & 3u;
-					const float split = __uint_as_float(nd.x);
-					const float oa = sel3(co, axis), da = sel3(cd, axis);
-					const float split_dist = (split - oa) / da;
-					const bool has_l = nd.y & 4u, has_r = nd.y & 8u;
-					const uint32_t li = nd.y >> 4, ri = li + (has_l ? 1u : 0u);
-					const bool left_first = oa < split;
-					const uint32_t first = left_first ? li : ri, second = left_first ? ri : li;
-					const bool has_first = left_first ? has_l : has_r, has_second = left_first ? has_r : has_l;
-					bool has_next;
-					if (split_dist < 0 || split_dist > tmax) { node = first; has_next = has_first; }
-					else if (split_dist < tmin) { node = second; has_next = has_second; }
-					else {
-						if (has_second && sp < kRegStack + kSpillStack) {
-							if (sp >= kRegStack) spill_put(spill, sp - kRegStack, n2, m2);
-							n2 = n1; m2 = m1; n1 = n0; m1 = m0; n0 = second; m0 = split_dist;
-							sp++;
-						}
-						node = first; has_next = has_first;
-						tmax = split_dist;
-					}
-					if (!has_next) st = ST_POP;
-				}
-			}
-		}
-	}
-#ifdef PTX_STAMP
-	if ((threadIdx.x & 63u) == 0) {
-		atomicAdd(g_diag + 0, (unsigned long long)dg_tri_trips); atomicAdd(g_diag + 1, (unsigned long long)dg_adv_trips);
-		atomicAdd(g_diag + 2, (unsigned long long)dg_tri_lanes); atomicAdd(g_diag + 3, (unsigned long long)dg_adv_lanes);
-		atomicAdd(g_diag + 4, 1ull);
-	}
-#endif
-}
-
 // ------------------------------------------------------------------------------------ deferred models
 // scene_traverse makes the whole wave wait for every model that ANY of its 64 rays enters: on Cornell 9 % / 4 % / 3 % /
 // 1.5 % of the rays enter the two boxes, the light and the sphere, so their triangle loops run with a handful of
@@ -692,32 +525,29 @@ DEV bool shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, c
 }
 
 // ------------------------------------------------------------------------------------ LDS staging
-struct Staged { Geom g; const ShadeRec* shade; const VisitRec* visits; };
+struct Staged { Geom g; const ShadeRec* shade; };
 
 template <bool LDS>
 DEV Staged stage_geometry(const DevScene& S, unsigned char* smem) {
-	if constexpr (!LDS) return {{S.nodes, S.refs, S.tri_isect}, S.shade, S.visits};
+	if constexpr (!LDS) return {{S.nodes, S.refs, S.tri_isect}, S.shade};
 	else {
-		// [triangle records][shade records][visit records][KD nodes][leaf refs], each region a multiple of 16 B
+		// [triangle records][shade records][KD nodes][leaf refs], each region a multiple of 16 B
 		uint4* dst = reinterpret_cast<uint4*>(smem);
-		const uint32_t n_tri16 = S.n_tris * 3, n_shade16 = S.n_surfaces * 9, n_visit16 = S.n_surfaces * 2, n_node16 = (S.n_nodes + 1) / 2, n_ref16 = (S.n_refs + 3) / 4;
+		const uint32_t n_tri16 = S.n_tris * 3, n_shade16 = S.n_surfaces * 9, n_node16 = (S.n_nodes + 1) / 2, n_ref16 = (S.n_refs + 3) / 4;
 		const uint4* src_t = reinterpret_cast<const uint4*>(S.tri_isect);
 		const uint4* src_s = reinterpret_cast<const uint4*>(S.shade);
-		const uint4* src_v = reinterpret_cast<const uint4*>(S.visits);
 		const uint4* src_n = reinterpret_cast<const uint4*>(S.nodes);
 		const uint4* src_r = reinterpret_cast<const uint4*>(S.refs);
 		uint4* d_s = dst + n_tri16;
-		uint4* d_v = d_s + n_shade16;
-		uint4* d_n = d_v + n_visit16;
+		uint4* d_n = d_s + n_shade16;
 		uint4* d_r = d_n + n_node16;
 		for (uint32_t i = threadIdx.x; i < n_tri16; i += blockDim.x) dst[i] = src_t[i];
 		for (uint32_t i = threadIdx.x; i < n_shade16; i += blockDim.x) d_s[i] = src_s[i];
-		for (uint32_t i = threadIdx.x; i < n_visit16; i += blockDim.x) d_v[i] = src_v[i];
 		for (uint32_t i = threadIdx.x; i < n_node16; i += blockDim.x) d_n[i] = src_n[i];
 		for (uint32_t i = threadIdx.x; i < n_ref16; i += blockDim.x) d_r[i] = src_r[i];
 		__syncthreads();
 		return {{reinterpret_cast<const uint2*>(d_n), reinterpret_cast<const uint32_t*>(d_r), reinterpret_cast<const float4*>(dst)},
-		        reinterpret_cast<const ShadeRec*>(d_s), reinterpret_cast<const VisitRec*>(d_v)};
+		        reinterpret_cast<const ShadeRec*>(d_s)};
 	}
 }
 
@@ -728,7 +558,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 // Per wave and chunk of kChunk paths, every bounce is two sweeps over the wave's private ray stream:
 //   EXTEND: (generate or) load ray -> closest hit -> 16-byte hit record        (traversal state only in registers)
 //   SHADE : load ray + hit + path state -> BSDF, radiance, next ray -> compacted write (path state only)
-template <bool LDS, bool SUN, bool ALPHA, int NSPACE>
+template <bool LDS, bool SUN, bool ALPHA>
 __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParams P, PassBuffers B, const ModelRec* __restrict__ t_models, const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
 	DevScene S = S0;
 	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;  // see struct Tables
@@ -757,12 +587,9 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 			float4* qout = qbase + (size_t)((depth + 1u) & 1u) * (4u * kChunk);
 			const bool last = depth + 1 == P.bounces;
 
-#ifdef PTX_STAMP
-			const unsigned long long t_a = __builtin_amdgcn_s_memtime();
-#endif
 			// ---------------- EXTEND
 			// lists live in the unused part of the wave's stream area: hdist (kChunk words) + n_models lists
-			const bool defer = NSPACE == 0 && S.n_models <= kMaxDeferModels && S.n_models > 1 &&
+			const bool defer = S.n_models <= kMaxDeferModels && S.n_models > 1 &&
 			                   (uint32_t)S.n_models * kListCap + kChunk <= (kQueueFloat4PerWave - 9u * kChunk) * 4u;
 			uint32_t list_len = 0;   // lane m: entries in model m's deferred list
 			for (uint32_t base = 0; base < n_in; base += 64) {
@@ -784,8 +611,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 					}
 				}
 				SceneHit h;
-				if constexpr (NSPACE > 0) extend64<NSPACE>(S, g, st.shade, st.visits, o, d, active, h, spill);
-				else if (!defer) { if (active) scene_traverse(S, g, o, d, h, spill); }
+				if (!defer) { if (active) scene_traverse(S, g, o, d, h, spill); }
 				else {
 					// renderer::intersect's model loop with the rarely entered models set aside
 					h.dist = -1.0f; h.surface = -1; h.tri = 0; h.b1 = 0; h.b2 = 0;
@@ -861,9 +687,6 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-#ifdef PTX_STAMP
-			const unsigned long long t_b = __builtin_amdgcn_s_memtime();
-#endif
 			// ---------------- SHADE + wave-level stream compaction
 			uint32_t n_out = 0;
 			for (uint32_t base = 0; base < n_in; base += 64) {
@@ -903,513 +726,10 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 			n_in = n_out;
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#ifdef PTX_STAMP  // diagnostic build only: wave-cycles spent in each phase, summed over waves (never shipped)
-			const unsigned long long t_c = __builtin_amdgcn_s_memtime();
-			if (lane == 0) { atomicAdd(B.ray_counter + 1, t_b - t_a); atomicAdd(B.ray_counter + 2, t_c - t_b); }
-#endif
 		}
 	}
 	// ray counter: one atomic per wave
 	for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-	if (lane == 0 && rays) atomicAdd(B.ray_counter, (unsigned long long)rays);
-}
-
-// ------------------------------------------------------------------------------------ integrator kernel, cooperative form
-// Same estimator, same per-ray arithmetic, different schedule (scenes without sun light / alpha, with <= 64 surfaces
-// and <= 2 ray spaces; everything else runs k_render_pass above).
-//
-// Stream entry of a live path (SoA of float4 arrays, wave-private, kChunk entries per array):
-//   A0 = world dir.xyz, path id | A1 = T.xyz, L.x | A2 = L.y, L.z, surface mask (2 words)
-//   per ray space k: Bk0 = local origin.xyz, local dir.x | Bk1 = local dir.y, dir.z, 1/dir.x, 1/dir.y | Bk2 = 1/dir.z
-// i.e. the producer of a ray (camera generation or the shading of the previous vertex, both running with all lanes
-// busy) also does the ray's wave-uniform setup: local rays per space and the bit mask of surfaces whose boxes it meets.
-//
-// EXTEND then is one persistent loop per (chunk, depth): lanes pull rays from the stream as they finish (ballot +
-// prefix over the idle lanes, one load of the entry's traversal part), so a long traversal delays only its own lane.
-template <int NSPACE> struct LocalRays { V3 lo[NSPACE], ld[NSPACE], inv[NSPACE]; uint64_t mask; };
-
-template <int NSPACE>
-DEV void ray_setup(const DevScene& S, V3 o, V3 d, LocalRays<NSPACE>& r) {
-#pragma unroll
-	for (int k = 0; k < NSPACE; k++) {
-		const SpaceRec& sp = S.spaces[k];
-		r.lo[k] = mulmv(sp.inv_basis, o) + mk(sp.inv_origin[0], sp.inv_origin[1], sp.inv_origin[2]);
-		r.ld[k] = normalize(mulmv(sp.inv_basis, d));
-		r.inv[k] = mk(1.0f / r.ld[k].x, 1.0f / r.ld[k].y, 1.0f / r.ld[k].z);
-	}
-	uint64_t mask = 0;
-	for (int m = 0; m < S.n_models; m++) {
-		const ModelRec& M = S.models[m];
-		const bool s1 = NSPACE > 1 && S.model_space[m] != 0;  // wave-uniform
-		const V3 mo = s1 ? r.lo[NSPACE - 1] : r.lo[0], mi = s1 ? r.inv[NSPACE - 1] : r.inv[0];
-		float nr, fr;
-		const bool mh = aabb_test_inv(M.bmin, M.bmax, mo, mi, nr, fr);
-		for (int k = 0; k < M.n_surfaces; k++) {
-			const SurfaceRec& sf = S.surfaces[M.first_surface + k];
-			const bool sh = mh && aabb_test_inv(sf.bmin, sf.bmax, mo, mi, nr, fr);
-			mask |= sh ? (1ull << (M.first_surface + k)) : 0ull;
-		}
-	}
-	r.mask = mask;
-}
-
-template <int NSPACE>
-DEV void entry_store(float4* q, uint32_t pos, V3 dw, uint32_t id, V3 T, V3 L, const LocalRays<NSPACE>& r) {
-	q[pos] = make_float4(dw.x, dw.y, dw.z, __uint_as_float(id));
-	q[kChunk + pos] = make_float4(T.x, T.y, T.z, L.x);
-	q[2 * kChunk + pos] = make_float4(L.y, L.z, __uint_as_float((uint32_t)r.mask), __uint_as_float((uint32_t)(r.mask >> 32)));
-#pragma unroll
-	for (int k = 0; k < NSPACE; k++) {
-		q[(3 + 3 * k) * kChunk + pos] = make_float4(r.lo[k].x, r.lo[k].y, r.lo[k].z, r.ld[k].x);
-		q[(4 + 3 * k) * kChunk + pos] = make_float4(r.ld[k].y, r.ld[k].z, r.inv[k].x, r.inv[k].y);
-		q[(5 + 3 * k) * kChunk + pos] = make_float4(r.inv[k].z, 0.f, 0.f, 0.f);
-	}
-}
-
-constexpr uint32_t kRefillMin = 12;  // refill when at least this many lanes are idle (or nothing else is runnable)
-
-template <bool LDS, int NSPACE>
-__global__ void __launch_bounds__(kBlock) k_render_pass_coop(DevScene S0, RenderParams P, PassBuffers B, const ModelRec* __restrict__ t_models, const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
-	DevScene S = S0;
-	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;  // see struct Tables
-	const Staged stg = stage_geometry<LDS>(S, g_smem);
-	const Geom g = stg.g;
-	const ShadeRec* shade = stg.shade;
-	const float4* visits = reinterpret_cast<const float4*>(stg.visits);
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t wave_slot = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	constexpr uint32_t kArrays = 3 + 3 * NSPACE;
-	float4* qbase = B.queues + (size_t)wave_slot * (kQueueFloat4PerWave);
-	float4* hbuf = qbase + 2u * kArrays * kChunk;
-	const Spill spill{B.spill + (size_t)wave_slot * (kSpillStack * 64) + lane};
-	uint64_t rays = 0;  // wave-uniform count
-
-	for (;;) {
-		uint32_t chunk = 0;
-		if (lane == 0) chunk = atomicAdd(B.chunk_counter, 1u);
-		chunk = __builtin_amdgcn_readfirstlane(chunk);
-		const uint64_t first = (uint64_t)chunk * kChunk;
-		if (first >= P.n_paths) break;
-		uint32_t n_in = (uint32_t)((P.n_paths - first) < (uint64_t)kChunk ? (P.n_paths - first) : kChunk);
-
-		// ---------------- GENERATE: camera rays of the chunk (renderer.cpp:359-370), with their setup
-		for (uint32_t base = 0; base < n_in; base += 64) {
-			const uint32_t i = base + lane;
-			if (i < n_in) {
-				const uint32_t id = (uint32_t)first + i;  // id within the pass: sample-major, pixel-minor
-				const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
-				const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
-				V3 o, d;
-				camera_ray(S, P, px, py, P.sample0 + s_local, o, d);
-				LocalRays<NSPACE> lr;
-				ray_setup<NSPACE>(S, o, d, lr);
-				entry_store<NSPACE>(qbase, i, d, id, mk(1, 1, 1), mk(0, 0, 0), lr);
-			}
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-		for (uint32_t depth = 0; depth < P.bounces && n_in > 0; depth++) {
-			float4* qin = qbase + (size_t)(depth & 1u) * (kArrays * kChunk);
-			float4* qout = qbase + (size_t)((depth + 1u) & 1u) * (kArrays * kChunk);
-			const bool last = depth + 1 == P.bounces;
-			rays += n_in;
-#ifdef PTX_STAMP
-			if (lane == 0) atomicAdd(g_diag + 4, (unsigned long long)n_in);
-#endif
-
-			// ---------------- EXTEND: persistent traversal, lanes refill from the stream
-			{
-				uint32_t next = 0;                       // wave-uniform: first stream entry not yet taken
-				uint32_t idx = 0;
-				uint32_t st = ST_DONE;
-				V3 lo[NSPACE], ld[NSPACE], inv[NSPACE];
-#pragma unroll
-				for (int k = 0; k < NSPACE; k++) { lo[k] = mk(0, 0, 0); ld[k] = mk(0, 0, 1); inv[k] = mk(0, 0, 0); }
-				uint64_t mask = 0;
-				int cur_model = -1, cur_surf = -1;
-				V3 co = mk(0, 0, 0), cd = mk(0, 0, 1);
-				float nt = -1.0f, nb1 = 0, nb2 = 0; uint32_t ntri = 0; int nsurf = -1;
-				float bdist = -1.0f, bb1 = 0, bb2 = 0; uint32_t btri = 0; int bsurf = -1;
-				uint32_t node = 0; float tmin = 0, tmax = 0, tfar = 0; int sp = 0;
-				uint32_t n0 = 0, n1 = 0, n2 = 0; float m0 = 0, m1 = 0, m2 = 0;
-				uint32_t rcur = 0, rend = 0; float lt = -1.0f, lb1 = 0, lb2 = 0; uint32_t ltri = 0;
-
-				for (;;) {
-					const bool want_tri = rcur < rend;
-					const bool idle = st == ST_DONE;
-					const bool want_adv = !want_tri && !idle;
-					const uint64_t mt = __ballot(want_tri), ma = __ballot(want_adv), mi = __ballot(idle);
-					const uint32_t ct = (uint32_t)__popcll(mt), ca = (uint32_t)__popcll(ma), ci = (uint32_t)__popcll(mi);
-#ifdef PTX_STAMP
-					if (lane == 0) {
-						const bool rf = next < n_in && ci != 0 && (ci >= kRefillMin || (mt | ma) == 0);
-						if (rf) { atomicAdd(g_diag + 5, 1ull); atomicAdd(g_diag + 6, (unsigned long long)ci); }
-						else if ((mt | ma) != 0) {
-							if (ct >= ca) { atomicAdd(g_diag + 0, 1ull); atomicAdd(g_diag + 2, (unsigned long long)ct); }
-							else { atomicAdd(g_diag + 1, 1ull); atomicAdd(g_diag + 3, (unsigned long long)ca); }
-						}
-					}
-#endif
-					if (next < n_in && ci != 0 && (ci >= kRefillMin || (mt | ma) == 0)) {
-						// ---------------- REFILL: idle lanes take the next stream entries
-						if (idle) {
-							const uint32_t my = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
-							if (my < n_in) {
-								const float4 a2 = qin[2 * kChunk + my];
-								mask = (uint64_t)__float_as_uint(a2.z) | ((uint64_t)__float_as_uint(a2.w) << 32);
-#pragma unroll
-								for (int k = 0; k < NSPACE; k++) {
-									const float4 b0 = qin[(3 + 3 * k) * kChunk + my], b1 = qin[(4 + 3 * k) * kChunk + my], b2 = qin[(5 + 3 * k) * kChunk + my];
-									lo[k] = mk(b0.x, b0.y, b0.z); ld[k] = mk(b0.w, b1.x, b1.y); inv[k] = mk(b1.z, b1.w, b2.x);
-								}
-								idx = my;
-								st = ST_NEXT; cur_model = -1; nt = -1.0f; bdist = -1.0f; bsurf = -1; btri = 0; bb1 = 0; bb2 = 0;
-							}
-						}
-						next += ci;
-						continue;
-					}
-					if ((mt | ma) == 0) break;
-					if (ct >= ca) {
-						// ---------------- TRI: one leaf triangle (mesh.cpp:381-389; ties keep the first)
-						if (want_tri) {
-							const uint32_t ti = g.refs[rcur];
-							const float4 A = g.tris[3 * ti], E1 = g.tris[3 * ti + 1], E2 = g.tris[3 * ti + 2];
-							float be, ga;
-							const float t = tri_test_pre(A, E1, E2, co, cd, be, ga);
-							if (t >= 0 && t <= tmax && (t < lt || !(lt >= 0))) { lt = t; lb1 = be; lb2 = ga; ltri = ti; }
-							rcur++;
-						}
-					} else if (want_adv) {
-						// ---------------- ADVANCE
-						if (st == ST_LEAF) {
-							if (lt >= 0) {   // the leaf produced a hit: mesh::intersect returns it (mesh.cpp:397-401)
-								if (lt < nt || !(nt >= 0)) { nt = lt; nb1 = lb1; nb2 = lb2; ntri = ltri; nsurf = cur_surf; }   // model.cpp:45-49
-								st = ST_NEXT;
-							} else st = ST_POP;
-						}
-						if (st == ST_POP) {
-							if (sp == 0) st = ST_NEXT;
-							else {
-								sp--;
-								node = n0; tmin = m0;
-								n0 = n1; m0 = m1; n1 = n2; m1 = m2;
-								if (sp >= kRegStack) spill_get(spill, sp - kRegStack, n2, m2);
-								tmax = sp > 0 ? m0 : tfar;
-								st = ST_NODE;
-							}
-						}
-						if (st == ST_NEXT) {
-							const bool more = mask != 0;
-							const int s = more ? (int)__builtin_ctzll(mask) : 0;
-							uint32_t ms = 0; float4 v0 = make_float4(0, 0, 0, 0), v1 = v0;
-							if (more) { v0 = visits[2 * s]; v1 = visits[2 * s + 1]; ms = __float_as_uint(v1.w); }
-							const int model = more ? (int)(ms & 0xFFFFFFu) : -2;
-							if (model != cur_model) {
-								if (nt >= 0) {   // close the model: local -> world distance (model.cpp:62-63), then renderer.cpp:663-669
-									const ShadeRec& R = shade[nsurf];
-									const float wd = length(mulmv(R.basis, cd * nt));
-									if (wd >= 0 && (wd < bdist || !(bdist >= 0))) { bdist = wd; bsurf = nsurf; btri = ntri; bb1 = nb1; bb2 = nb2; }
-								}
-								nt = -1.0f;
-								cur_model = model;
-							}
-							if (!more) {
-								hbuf[idx] = make_float4(__int_as_float(bsurf), __uint_as_float(btri), bb1, bb2);
-								st = ST_DONE;
-							} else {
-								mask &= mask - 1;
-								cur_surf = s;
-								const bool s1 = NSPACE > 1 && (ms >> 24) != 0;
-								co = s1 ? lo[NSPACE - 1] : lo[0];
-								cd = s1 ? ld[NSPACE - 1] : ld[0];
-								const V3 civ = s1 ? inv[NSPACE - 1] : inv[0];
-								const float bmn[3] = {v0.x, v0.y, v0.z}, bmx[3] = {v1.x, v1.y, v1.z};
-								float nr, fr;
-								aabb_test_inv(bmn, bmx, co, civ, nr, fr);   // the hit is known from the mask; the distances are needed
-								node = __float_as_uint(v0.w); tmin = nr; tmax = fr; tfar = fr; sp = 0;
-								st = ST_NODE;
-							}
-						}
-						// descend to a leaf (mesh.cpp:313-370): the lanes of this section loop together
-						while (st == ST_NODE) {
-#ifdef PTX_STAMP
-							if (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(true) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(true), 0u)) == 0) atomicAdd(g_diag + 7, 1ull);
-#endif
-							const uint2 nd = g.nodes[node];
-							if ((nd.y & 3u) == KD_LEAF) {
-								rcur = nd.x; rend = nd.x + (nd.y >> 2);
-								lt = -1.0f;
-								st = ST_LEAF;
-							} else {
-								const uint32_t axis = nd.y & 3u;
-								const float split = __uint_as_float(nd.x);
-								const float oa = sel3(co, axis), da = sel3(cd, axis);
-								const float split_dist = (split - oa) / da;
-								const bool has_l = nd.y & 4u, has_r = nd.y & 8u;
-								const uint32_t li = nd.y >> 4, ri = li + (has_l ? 1u : 0u);
-								const bool left_first = oa < split;
-								const uint32_t first_c = left_first ? li : ri, second = left_first ? ri : li;
-								const bool has_first = left_first ? has_l : has_r, has_second = left_first ? has_r : has_l;
-								bool has_next;
-								if (split_dist < 0 || split_dist > tmax) { node = first_c; has_next = has_first; }
-								else if (split_dist < tmin) { node = second; has_next = has_second; }
-								else {
-									if (has_second && sp < kRegStack + kSpillStack) {
-										if (sp >= kRegStack) spill_put(spill, sp - kRegStack, n2, m2);
-										n2 = n1; m2 = m1; n1 = n0; m1 = m0; n0 = second; m0 = split_dist;
-										sp++;
-									}
-									node = first_c; has_next = has_first;
-									tmax = split_dist;
-								}
-								if (!has_next) st = ST_POP;
-							}
-						}
-					}
-				}
-			}
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-			// ---------------- SHADE + wave-level stream compaction (+ setup of the next ray)
-			uint32_t n_out = 0;
-			for (uint32_t base = 0; base < n_in; base += 64) {
-				const uint32_t i = base + lane;
-				const bool active = i < n_in;
-				V3 o = {0, 0, 0}, d = {0, 0, 1}, T = {1, 1, 1}, L = {0, 0, 0};
-				uint32_t id = 0;
-				bool alive = false;
-				if (active) {
-					const float4 a0 = qin[i], a1 = qin[kChunk + i], a2 = qin[2 * kChunk + i], hq = hbuf[i];
-					d = mk(a0.x, a0.y, a0.z); id = __float_as_uint(a0.w);
-					T = mk(a1.x, a1.y, a1.z); L = mk(a1.w, a2.x, a2.y);
-					SceneHit h;
-					h.dist = 0; h.surface = __float_as_int(hq.x); h.tri = __float_as_uint(hq.y); h.b1 = hq.z; h.b2 = hq.w;
-					const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
-					const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
-					uint32_t unused_rays = 0;
-					alive = shade_vertex<false, false>(S, g, shade, P, py * P.W + px, P.sample0 + s_local, depth, h, o, d, T, L, unused_rays, spill);
-					if (last) alive = false;  // trace(0, ..) returns black: renderer.cpp:438-439
-					if (!alive) B.sample_rad[id] = make_float4(L.x, L.y, L.z, 1.0f);
-				}
-				const uint64_t mk_alive = __ballot(alive);
-				if (alive) {
-					const uint32_t pos = n_out + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk_alive >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk_alive, 0u));
-					LocalRays<NSPACE> lr;
-					ray_setup<NSPACE>(S, o, d, lr);
-					entry_store<NSPACE>(qout, pos, d, id, T, L, lr);
-				}
-				n_out += (uint32_t)__popcll(mk_alive);
-			}
-			n_in = n_out;
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		}
-	}
-	if (lane == 0 && rays) atomicAdd(B.ray_counter, (unsigned long long)rays);
-}
-
-// ------------------------------------------------------------------------------------ integrator kernel, mask-sorted form
-// The per-lane traversal of k_render_pass pays, for every group of 64 rays, the slowest lane of EVERY model any lane
-// touches: on Cornell a ray meets 2-3 of the 7 surface boxes, the wave meets all of them (37 % lane utilisation).
-// Here every live ray carries the bit mask of surfaces whose boxes it meets (computed by its producer, all lanes busy),
-// and before each EXTEND sweep the wave counting-sorts its chunk by an 8-bit key made of the mask bits of the most
-// expensive surfaces (LDS bins, ds_add_rtn; ~30 instructions per 64 rays). Lanes of one wave-iteration then share
-// their masks, whole models are skipped by the exec mask, and the leaf-triangle loops run with nearly full waves.
-// Arithmetic per ray is unchanged (same visiting order, same operations): results are bit-identical.
-// Stream entry (SoA of float4 arrays x kChunk): A0 = world dir, id | A1 = T, L.x | A2 = L.y, L.z, mask |
-//   per space k: (lo.xyz, ld.x), (ld.y, ld.z, inv.x, inv.y) | C = inv.z of space 0, 1
-template <int NSPACE>
-DEV void entry_store_s(float4* q, uint32_t pos, V3 dw, uint32_t id, V3 T, V3 L, const LocalRays<NSPACE>& r) {
-	q[pos] = make_float4(dw.x, dw.y, dw.z, __uint_as_float(id));
-	q[kChunk + pos] = make_float4(T.x, T.y, T.z, L.x);
-	q[2 * kChunk + pos] = make_float4(L.y, L.z, __uint_as_float((uint32_t)r.mask), __uint_as_float((uint32_t)(r.mask >> 32)));
-#pragma unroll
-	for (int k = 0; k < NSPACE; k++) {
-		q[(3 + 2 * k) * kChunk + pos] = make_float4(r.lo[k].x, r.lo[k].y, r.lo[k].z, r.ld[k].x);
-		q[(4 + 2 * k) * kChunk + pos] = make_float4(r.ld[k].y, r.ld[k].z, r.inv[k].x, r.inv[k].y);
-	}
-	q[(3 + 2 * NSPACE) * kChunk + pos] = make_float4(r.inv[0].z, r.inv[NSPACE - 1].z, 0.f, 0.f);
-}
-
-// closest hit with the surface mask: renderer::intersect / model::intersect order, boxes already tested
-template <int NSPACE>
-DEV void scene_traverse_masked(const DevScene& S, const Geom& g, const V3* lo, const V3* ld, const V3* inv, uint64_t mask,
-                               SceneHit& best, const Spill& spill) {
-	best.dist = -1.0f; best.surface = -1; best.tri = 0; best.b1 = 0; best.b2 = 0;
-	for (int m = 0; m < S.n_models; m++) {
-		const ModelRec& M = S.models[m];
-		const uint64_t mm = (mask >> M.first_surface) & (M.n_surfaces >= 64 ? ~0ull : ((1ull << M.n_surfaces) - 1ull));
-		if (mm == 0) continue;
-		const bool s1 = NSPACE > 1 && S.model_space[m] != 0;  // wave-uniform
-		const V3 mo = s1 ? lo[NSPACE - 1] : lo[0], md = s1 ? ld[NSPACE - 1] : ld[0], mi = s1 ? inv[NSPACE - 1] : inv[0];
-		MeshHit nearest;
-		nearest.t = -1.0f;
-		int hit_surface = -1;
-		for (int k = 0; k < M.n_surfaces; k++) {
-			if (!((mm >> k) & 1ull)) continue;
-			MeshHit h;
-			if (!mesh_traverse(g, S.surfaces[M.first_surface + k], mo, md, mi, h, spill)) continue;
-			if (h.t < nearest.t || !(nearest.t >= 0)) { nearest = h; hit_surface = M.first_surface + k; }
-		}
-		if (!(nearest.t >= 0)) continue;
-		const float wd = length(mulmv(M.basis, md * nearest.t));
-		if (!(wd >= 0)) continue;
-		if (wd < best.dist || !(best.dist >= 0)) { best.dist = wd; best.surface = hit_surface; best.tri = nearest.tri; best.b1 = nearest.b1; best.b2 = nearest.b2; }
-	}
-}
-
-template <bool LDS, int NSPACE>
-__global__ void __launch_bounds__(kBlock) k_render_pass_sorted(DevScene S0, RenderParams P, PassBuffers B, uint32_t bins_offset, const ModelRec* __restrict__ t_models, const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
-	DevScene S = S0;
-	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;  // see struct Tables
-	const Staged stg = stage_geometry<LDS>(S, g_smem);
-	const Geom g = stg.g;
-	const ShadeRec* shade = stg.shade;
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t wave_in_block = threadIdx.x >> 6;
-	const uint32_t wave_slot = blockIdx.x * (kBlock / 64) + wave_in_block;
-	constexpr uint32_t kArrays = 4 + 2 * NSPACE;
-	float4* qbase = B.queues + (size_t)wave_slot * (kQueueFloat4PerWave);
-	float4* hbuf = qbase + 2u * kArrays * kChunk;
-	uint32_t* perm = reinterpret_cast<uint32_t*>(hbuf + kChunk);   // [kChunk]
-	uint32_t* tmp = perm + kChunk;                                 // [kChunk]
-	uint32_t* bins = reinterpret_cast<uint32_t*>(g_smem + bins_offset) + wave_in_block * 256u;   // this wave's 256 counters
-	const Spill spill{B.spill + (size_t)wave_slot * (kSpillStack * 64) + lane};
-	uint64_t rays = 0;  // wave-uniform count
-
-	for (;;) {
-		uint32_t chunk = 0;
-		if (lane == 0) chunk = atomicAdd(B.chunk_counter, 1u);
-		chunk = __builtin_amdgcn_readfirstlane(chunk);
-		const uint64_t first = (uint64_t)chunk * kChunk;
-		if (first >= P.n_paths) break;
-		uint32_t n_in = (uint32_t)((P.n_paths - first) < (uint64_t)kChunk ? (P.n_paths - first) : kChunk);
-
-		// ---------------- GENERATE: camera rays of the chunk (renderer.cpp:359-370), with their setup
-		for (uint32_t base = 0; base < n_in; base += 64) {
-			const uint32_t i = base + lane;
-			if (i < n_in) {
-				const uint32_t id = (uint32_t)first + i;  // id within the pass: sample-major, pixel-minor
-				const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
-				const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
-				V3 o, d;
-				camera_ray(S, P, px, py, P.sample0 + s_local, o, d);
-				LocalRays<NSPACE> lr;
-				ray_setup<NSPACE>(S, o, d, lr);
-				entry_store_s<NSPACE>(qbase, i, d, id, mk(1, 1, 1), mk(0, 0, 0), lr);
-			}
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-		for (uint32_t depth = 0; depth < P.bounces && n_in > 0; depth++) {
-			float4* qin = qbase + (size_t)(depth & 1u) * (kArrays * kChunk);
-			float4* qout = qbase + (size_t)((depth + 1u) & 1u) * (kArrays * kChunk);
-			const bool last = depth + 1 == P.bounces;
-			rays += n_in;
-
-#ifdef PTX_STAMP
-			const unsigned long long t_0 = __builtin_amdgcn_s_memtime();
-#endif
-			// ---------------- SORT: counting sort of the chunk by the surface-mask key
-			for (uint32_t k = lane; k < 256u; k += 64u) bins[k] = 0u;
-			for (uint32_t base = 0; base < n_in; base += 64) {
-				const uint32_t i = base + lane;
-				if (i < n_in) {
-					const float4 a2 = qin[2 * kChunk + i];
-					const uint64_t mask = (uint64_t)__float_as_uint(a2.z) | ((uint64_t)__float_as_uint(a2.w) << 32);
-					uint32_t key = 0;
-					for (uint32_t k = 0; k < S.n_key; k++) key |= (uint32_t)((mask >> S.key_surf[k]) & 1ull) << k;
-					const uint32_t r = atomicAdd(&bins[key], 1u);     // ds_add_rtn_u32: rank inside the bin
-					tmp[i] = key | (r << 8);
-				}
-			}
-			{   // exclusive scan of the 256 counters: 4 per lane + wave scan
-				const uint32_t c0 = bins[4 * lane], c1 = bins[4 * lane + 1], c2 = bins[4 * lane + 2], c3 = bins[4 * lane + 3];
-				const uint32_t tot = c0 + c1 + c2 + c3;
-				uint32_t incl = tot;
-				for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if ((int)lane >= off) incl += v; }
-				const uint32_t ex = incl - tot;
-				bins[4 * lane] = ex; bins[4 * lane + 1] = ex + c0; bins[4 * lane + 2] = ex + c0 + c1; bins[4 * lane + 3] = ex + c0 + c1 + c2;
-			}
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-			for (uint32_t base = 0; base < n_in; base += 64) {
-				const uint32_t i = base + lane;
-				if (i < n_in) { const uint32_t v = tmp[i]; perm[bins[v & 255u] + (v >> 8)] = i; }
-			}
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-#ifdef PTX_STAMP
-			const unsigned long long t_1 = __builtin_amdgcn_s_memtime();
-#endif
-			// ---------------- EXTEND in sorted order
-			for (uint32_t base = 0; base < n_in; base += 64) {
-				const uint32_t pos = base + lane;
-				if (pos < n_in) {
-					const uint32_t i = perm[pos];
-					const float4 a2 = qin[2 * kChunk + i], cz = qin[(3 + 2 * NSPACE) * kChunk + i];
-					const uint64_t mask = (uint64_t)__float_as_uint(a2.z) | ((uint64_t)__float_as_uint(a2.w) << 32);
-					V3 lo[NSPACE], ld[NSPACE], inv[NSPACE];
-#pragma unroll
-					for (int k = 0; k < NSPACE; k++) {
-						const float4 b0 = qin[(3 + 2 * k) * kChunk + i], b1 = qin[(4 + 2 * k) * kChunk + i];
-						lo[k] = mk(b0.x, b0.y, b0.z); ld[k] = mk(b0.w, b1.x, b1.y); inv[k] = mk(b1.z, b1.w, k == 0 ? cz.x : cz.y);
-					}
-					SceneHit h;
-					scene_traverse_masked<NSPACE>(S, g, lo, ld, inv, mask, h, spill);
-					hbuf[i] = make_float4(__int_as_float(h.surface), __uint_as_float(h.tri), h.b1, h.b2);
-				}
-			}
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-#ifdef PTX_STAMP
-			const unsigned long long t_2 = __builtin_amdgcn_s_memtime();
-#endif
-			// ---------------- SHADE + wave-level stream compaction (+ setup of the next ray)
-			uint32_t n_out = 0;
-			for (uint32_t base = 0; base < n_in; base += 64) {
-				const uint32_t i = base + lane;
-				const bool active = i < n_in;
-				V3 o = {0, 0, 0}, d = {0, 0, 1}, T = {1, 1, 1}, L = {0, 0, 0};
-				uint32_t id = 0;
-				bool alive = false;
-				if (active) {
-					const float4 a0 = qin[i], a1 = qin[kChunk + i], a2 = qin[2 * kChunk + i], hq = hbuf[i];
-					d = mk(a0.x, a0.y, a0.z); id = __float_as_uint(a0.w);
-					T = mk(a1.x, a1.y, a1.z); L = mk(a1.w, a2.x, a2.y);
-					SceneHit h;
-					h.dist = 0; h.surface = __float_as_int(hq.x); h.tri = __float_as_uint(hq.y); h.b1 = hq.z; h.b2 = hq.w;
-					const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
-					const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
-					uint32_t unused_rays = 0;
-					alive = shade_vertex<false, false>(S, g, shade, P, py * P.W + px, P.sample0 + s_local, depth, h, o, d, T, L, unused_rays, spill);
-					if (last) alive = false;  // trace(0, ..) returns black: renderer.cpp:438-439
-					if (!alive) B.sample_rad[id] = make_float4(L.x, L.y, L.z, 1.0f);
-				}
-				const uint64_t mk_alive = __ballot(alive);
-				if (alive) {
-					const uint32_t pos = n_out + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk_alive >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk_alive, 0u));
-					LocalRays<NSPACE> lr;
-					ray_setup<NSPACE>(S, o, d, lr);
-					entry_store_s<NSPACE>(qout, pos, d, id, T, L, lr);
-				}
-				n_out += (uint32_t)__popcll(mk_alive);
-			}
-			n_in = n_out;
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#ifdef PTX_STAMP
-			const unsigned long long t_3 = __builtin_amdgcn_s_memtime();
-			if (lane == 0) { atomicAdd(g_diag + 0, t_1 - t_0); atomicAdd(g_diag + 1, t_2 - t_1); atomicAdd(g_diag + 2, t_3 - t_2); }
-#endif
-		}
-	}
 	if (lane == 0 && rays) atomicAdd(B.ray_counter, (unsigned long long)rays);
 }
 
@@ -1426,7 +746,7 @@ __global__ void k_resolve(const float4* __restrict__ sample_rad, float4* __restr
 }
 
 // ------------------------------------------------------------------------------------ batch intersect
-template <bool LDS, int NSPACE>
+template <bool LDS>
 __global__ void __launch_bounds__(kBlock) k_intersect_batch(DevScene S0, IntersectArgs A, const ModelRec* __restrict__ t_models, const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
 	DevScene S = S0;
 	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;  // see struct Tables
@@ -1434,16 +754,10 @@ __global__ void __launch_bounds__(kBlock) k_intersect_batch(DevScene S0, Interse
 	const Geom g = st.g;
 	const Spill spill{A.spill + (size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * (kSpillStack * 64) + (threadIdx.x & 63u)};
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
-	const size_t n_round = (A.n + stride - 1) / stride * stride;   // every wave makes the same number of trips (extend64 is wave-cooperative)
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-		const bool active = i < A.n;
-		V3 o = {0, 0, 0}, d = {0, 0, 1};
-		if (active) { o = mk(A.ox[i], A.oy[i], A.oz[i]); d = mk(A.dx[i], A.dy[i], A.dz[i]); }
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += stride) {
+		const V3 o = mk(A.ox[i], A.oy[i], A.oz[i]), d = mk(A.dx[i], A.dy[i], A.dz[i]);
 		SceneHit h;
-		if constexpr (NSPACE > 0) extend64<NSPACE>(S, g, st.shade, st.visits, o, d, active, h, spill);
-		else if (active) scene_traverse(S, g, o, d, h, spill);
-		if (!active) continue;
-		const bool hit = h.surface >= 0;
+		const bool hit = scene_traverse(S, g, o, d, h, spill);
 		A.distance[i] = hit ? h.dist : -1.0f;
 		A.surface[i] = hit ? h.surface : -1;
 		A.triangle[i] = hit ? (int32_t)(h.tri - S.surfaces[h.surface].tri_base) : -1;
@@ -1489,52 +803,14 @@ static hipError_t set_lds(const void* fn, size_t bytes) {
 	return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <bool LDS, bool SUN, bool ALPHA, int NSPACE>
+template <bool LDS, bool SUN, bool ALPHA>
 static hipError_t launch_pass_variant(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
 	if (LDS) {
-		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<LDS, SUN, ALPHA, NSPACE>), lds_bytes);
+		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<LDS, SUN, ALPHA>), lds_bytes);
 		if (e != hipSuccess) return e;
 	}
-	hipLaunchKernelGGL((k_render_pass<LDS, SUN, ALPHA, NSPACE>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B, S.models, S.surfaces, S.spaces, S.model_space);
+	hipLaunchKernelGGL((k_render_pass<LDS, SUN, ALPHA>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B, S.models, S.surfaces, S.spaces, S.model_space);
 	return hipGetLastError();
-}
-template <bool LDS, int NSPACE>
-static hipError_t launch_coop(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
-	if (LDS) {
-		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass_coop<LDS, NSPACE>), lds_bytes);
-		if (e != hipSuccess) return e;
-	}
-	hipLaunchKernelGGL((k_render_pass_coop<LDS, NSPACE>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B, S.models, S.surfaces, S.spaces, S.model_space);
-	return hipGetLastError();
-}
-template <bool LDS, int NSPACE>
-static hipError_t launch_sorted(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
-	const size_t geo = LDS ? lds_bytes : 0, total = geo + (size_t)(kBlock / 64) * 256 * 4;
-	hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass_sorted<LDS, NSPACE>), total);
-	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL((k_render_pass_sorted<LDS, NSPACE>), dim3(grid), dim3(kBlock), total, stream, S, P, B, (uint32_t)geo, S.models, S.surfaces, S.spaces, S.model_space);
-	return hipGetLastError();
-}
-template <bool LDS, bool SUN, bool ALPHA>
-static hipError_t launch_pass_space(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
-	// wave-cooperative traversal needs the surface mask in 64 bits and the local rays of all spaces in registers
-	// Schedules of the same arithmetic (bit-identical results): per-lane traversal (default: fastest today), and two
-	// experimental ones kept for comparison: PTX_SORTED=1 (chunk counting-sorted by surface mask) and PTX_COOP=1
-	// (wave-cooperative state machine with lane refill).
-	static const bool want_coop = getenv("PTX_COOP") != nullptr, want_sorted = getenv("PTX_SORTED") != nullptr;
-	const bool fast = (want_coop || want_sorted) && S.n_surfaces <= (uint32_t)kMaxFastSurfaces && S.n_spaces <= (uint32_t)kMaxFastSpaces;
-	if constexpr (!SUN && !ALPHA) {
-		if (fast && want_coop) {
-			if (S.n_spaces <= 1) return launch_coop<LDS, 1>(S, P, B, lds_bytes, grid, stream);
-			return launch_coop<LDS, 2>(S, P, B, lds_bytes, grid, stream);
-		}
-		const size_t sort_lds = (size_t)(kBlock / 64) * 256 * 4;
-		if (fast && (!LDS || lds_bytes + sort_lds <= 160 * 1024)) {
-			if (S.n_spaces <= 1) return launch_sorted<LDS, 1>(S, P, B, lds_bytes, grid, stream);
-			return launch_sorted<LDS, 2>(S, P, B, lds_bytes, grid, stream);
-		}
-	}
-	return launch_pass_variant<LDS, SUN, ALPHA, 0>(S, P, B, lds_bytes, grid, stream);
 }
 
 hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, bool lds, size_t lds_bytes, int grid,
@@ -1542,50 +818,29 @@ hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const Pa
 	const bool sun = S.sun.present != 0, alpha = S.any_alpha != 0;
 	const int v = (lds ? 4 : 0) | (sun ? 2 : 0) | (alpha ? 1 : 0);
 	switch (v) {
-	case 0: return launch_pass_space<false, false, false>(S, P, B, lds_bytes, grid, stream);
-	case 1: return launch_pass_space<false, false, true>(S, P, B, lds_bytes, grid, stream);
-	case 2: return launch_pass_space<false, true, false>(S, P, B, lds_bytes, grid, stream);
-	case 3: return launch_pass_space<false, true, true>(S, P, B, lds_bytes, grid, stream);
-	case 4: return launch_pass_space<true, false, false>(S, P, B, lds_bytes, grid, stream);
-	case 5: return launch_pass_space<true, false, true>(S, P, B, lds_bytes, grid, stream);
-	case 6: return launch_pass_space<true, true, false>(S, P, B, lds_bytes, grid, stream);
-	default: return launch_pass_space<true, true, true>(S, P, B, lds_bytes, grid, stream);
+	case 0: return launch_pass_variant<false, false, false>(S, P, B, lds_bytes, grid, stream);
+	case 1: return launch_pass_variant<false, false, true>(S, P, B, lds_bytes, grid, stream);
+	case 2: return launch_pass_variant<false, true, false>(S, P, B, lds_bytes, grid, stream);
+	case 3: return launch_pass_variant<false, true, true>(S, P, B, lds_bytes, grid, stream);
+	case 4: return launch_pass_variant<true, false, false>(S, P, B, lds_bytes, grid, stream);
+	case 5: return launch_pass_variant<true, false, true>(S, P, B, lds_bytes, grid, stream);
+	case 6: return launch_pass_variant<true, true, false>(S, P, B, lds_bytes, grid, stream);
+	default: return launch_pass_variant<true, true, true>(S, P, B, lds_bytes, grid, stream);
 	}
 }
-#ifdef PTX_STAMP
-void diag_dump() {
-	unsigned long long h[8];
-	if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof h) != hipSuccess) return;
-	fprintf(stderr, "[PTX_STAMP] sorted kernel wave-cycles: sort %.3g  extend %.3g  shade %.3g\n", (double)h[0], (double)h[1], (double)h[2]);
-	const double per64 = h[4] / 64.0;
-	fprintf(stderr, "[PTX_STAMP] rays=%llu  per 64 rays: tri trips %.2f (%.1f lanes), adv trips %.2f (%.1f lanes), refill trips %.2f (%.1f lanes), node-loop iters %.2f\n", h[4],
-	        h[0] / per64, (double)h[2] / (h[0] ? h[0] : 1), h[1] / per64, (double)h[3] / (h[1] ? h[1] : 1), h[5] / per64, (double)h[6] / (h[5] ? h[5] : 1), h[7] / per64);
-}
-#endif
 hipError_t launch_resolve(const float4* sample_rad, float4* accum, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream) {
 	hipLaunchKernelGGL(k_resolve, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, sample_rad, accum, n_pixels, pass_spp);
 	return hipGetLastError();
 }
-template <bool LDS, int NSPACE>
-static hipError_t launch_intersect_variant(const DevScene& S, const IntersectArgs& A, size_t lds_bytes, int grid, hipStream_t stream) {
-	if (LDS) {
-		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_intersect_batch<LDS, NSPACE>), lds_bytes);
-		if (e != hipSuccess) return e;
-	}
-	hipLaunchKernelGGL((k_intersect_batch<LDS, NSPACE>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, A, S.models, S.surfaces, S.spaces, S.model_space);
-	return hipGetLastError();
-}
 hipError_t launch_intersect(const DevScene& S, const IntersectArgs& A, bool lds, size_t lds_bytes, int grid, hipStream_t stream) {
-	const bool fast = S.n_surfaces <= (uint32_t)kMaxFastSurfaces && S.n_spaces <= (uint32_t)kMaxFastSpaces;
-	const int ns = !fast ? 0 : (S.n_spaces <= 1 ? 1 : 2);
 	if (lds) {
-		if (ns == 1) return launch_intersect_variant<true, 1>(S, A, lds_bytes, grid, stream);
-		if (ns == 2) return launch_intersect_variant<true, 2>(S, A, lds_bytes, grid, stream);
-		return launch_intersect_variant<true, 0>(S, A, lds_bytes, grid, stream);
+		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_intersect_batch<true>), lds_bytes);
+		if (e != hipSuccess) return e;
+		hipLaunchKernelGGL(k_intersect_batch<true>, dim3(grid), dim3(kBlock), lds_bytes, stream, S, A, S.models, S.surfaces, S.spaces, S.model_space);
+	} else {
+		hipLaunchKernelGGL(k_intersect_batch<false>, dim3(grid), dim3(kBlock), 0, stream, S, A, S.models, S.surfaces, S.spaces, S.model_space);
 	}
-	if (ns == 1) return launch_intersect_variant<false, 1>(S, A, lds_bytes, grid, stream);
-	if (ns == 2) return launch_intersect_variant<false, 2>(S, A, lds_bytes, grid, stream);
-	return launch_intersect_variant<false, 0>(S, A, lds_bytes, grid, stream);
+	return hipGetLastError();
 }
 hipError_t launch_tonemap(const float4* accum, uint32_t n_pixels, float spp, uchar4* out, hipStream_t stream) {
 	hipLaunchKernelGGL(k_tonemap, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, accum, n_pixels, spp, out);

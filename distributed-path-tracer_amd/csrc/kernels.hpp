@@ -15,8 +15,8 @@ constexpr int kBlock = PTX_BLOCK;  // threads per workgroup (one workgroup per C
 #define PTX_CHUNK 1024
 #endif
 constexpr uint32_t kChunk = PTX_CHUNK; // camera paths a wave takes per counter fetch (16 wave-iterations)
-// wave-private stream space, in float4: two ray buffers of up to 9 arrays + one hit-record array
-constexpr uint32_t kQueueFloat4PerWave = (2u * 9u + 1u) * kChunk;  // cooperative kernel: 3 + 3*2 arrays per buffer
+// wave-private stream space, in float4
+constexpr uint32_t kQueueFloat4PerWave = 19u * kChunk;  // 2 x 4 ray arrays + hit records (9), the rest: hit distances + deferred-model lists
 constexpr uint32_t kSpillWords = 24u * 64u;  // uint2 per wave: kSpillStack levels x 64 lanes
 
 // Device view of a FlatScene (all pointers are device pointers).
@@ -30,15 +30,12 @@ struct DevScene {
 	const float4* tri_isect; // 3 per triangle: intersection form (TriIsect)
 	const float4* vattr;  // 2 per vertex
 	const ShadeRec* shade; // 1 per surface
-	const VisitRec* visits; // 1 per surface, visit order
 	const SpaceRec* spaces; // distinct world->local transforms
 	const uint32_t* model_space; // per model
 	int32_t n_models;
 	uint32_t n_surfaces, n_nodes, n_refs, n_tris;
 	uint32_t any_alpha;
 	uint32_t n_spaces;
-	uint32_t n_key;          // surfaces whose mask bits form the sort key (<= 8), most expensive first
-	uint32_t key_surf[8];
 	CameraRec cam;
 	SunRec sun;
 };

@@ -16,9 +16,6 @@
 #include "kernels.hpp"
 
 using namespace ptx;
-#ifdef PTX_STAMP
-namespace ptx { void diag_dump(); }
-#endif
 
 namespace {
 
@@ -66,7 +63,7 @@ struct ptx_ctx {
 struct ptx_scene {
 	ptx_ctx* ctx = nullptr;
 	FlatScene host;
-	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr, d_isect, d_shade, d_visits, d_spaces, d_model_space;
+	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr, d_isect, d_shade, d_spaces, d_model_space;
 	DevScene dev{};
 	bool lds = false;
 	size_t lds_bytes = 0;
@@ -96,7 +93,6 @@ int upload_scene(ptx_scene* sc) {
 	HIP_TRY(up(sc->d_isect, h.tri_isect.data(), h.tri_isect.size() * 48, h.tri_isect.size() * 48));
 	HIP_TRY(up(sc->d_vattr, h.vattr.data(), h.vattr.size() * 32, h.vattr.size() * 32));
 	HIP_TRY(up(sc->d_shade, h.shade.data(), h.shade.size() * sizeof(ShadeRec), h.shade.size() * sizeof(ShadeRec)));
-	HIP_TRY(up(sc->d_visits, h.visits.data(), h.visits.size() * sizeof(VisitRec), h.visits.size() * sizeof(VisitRec)));
 	HIP_TRY(up(sc->d_spaces, h.spaces.data(), h.spaces.size() * sizeof(SpaceRec), h.spaces.size() * sizeof(SpaceRec)));
 	HIP_TRY(up(sc->d_model_space, h.model_space.data(), h.model_space.size() * 4, h.model_space.size() * 4));
 	HIP_TRY(hipStreamSynchronize(c->stream));
@@ -110,12 +106,9 @@ int upload_scene(ptx_scene* sc) {
 	d.vattr = (const float4*)sc->d_vattr.p;
 	d.tri_isect = (const float4*)sc->d_isect.p;
 	d.shade = (const ShadeRec*)sc->d_shade.p;
-	d.visits = (const VisitRec*)sc->d_visits.p;
 	d.spaces = (const SpaceRec*)sc->d_spaces.p;
 	d.model_space = (const uint32_t*)sc->d_model_space.p;
 	d.n_spaces = (uint32_t)h.spaces.size();
-	d.n_key = (uint32_t)h.key_surfaces.size();
-	for (uint32_t k = 0; k < 8; k++) d.key_surf[k] = k < d.n_key ? h.key_surfaces[k] : 0u;
 	d.n_surfaces = (uint32_t)h.surfaces.size();
 	d.any_alpha = h.any_alpha ? 1u : 0u;
 	d.n_models = (int32_t)h.models.size();
@@ -124,7 +117,7 @@ int upload_scene(ptx_scene* sc) {
 	d.n_tris = (uint32_t)h.tris.size();
 	d.cam = h.camera;
 	d.sun = h.sun;
-	sc->lds_bytes = h.tris.size() * 48 + h.shade.size() * (sizeof(ShadeRec) + sizeof(VisitRec)) + pad16(h.kd_nodes.size() * 8) + pad16(h.kd_refs.size() * 4);
+	sc->lds_bytes = h.tris.size() * 48 + h.shade.size() * sizeof(ShadeRec) + pad16(h.kd_nodes.size() * 8) + pad16(h.kd_refs.size() * 4);
 	sc->lds = sc->lds_bytes <= kLdsBudget;
 	return PTX_OK;
 }
@@ -136,7 +129,7 @@ int finish_scene(ptx_ctx* ctx, ptx_scene* sc, ptx_scene** out) {
 		int rc = upload_scene(sc);
 		if (rc != PTX_OK) { delete sc; return rc; }
 	} else {
-		sc->lds_bytes = sc->host.tris.size() * 48 + sc->host.shade.size() * (sizeof(ShadeRec) + sizeof(VisitRec)) + pad16(sc->host.kd_nodes.size() * 8) + pad16(sc->host.kd_refs.size() * 4);
+		sc->lds_bytes = sc->host.tris.size() * 48 + sc->host.shade.size() * sizeof(ShadeRec) + pad16(sc->host.kd_nodes.size() * 8) + pad16(sc->host.kd_refs.size() * 4);
 		sc->lds = sc->lds_bytes <= kLdsBudget;
 	}
 	*out = sc;
@@ -257,7 +250,7 @@ void ptx_scene_destroy(ptx_scene* sc) {
 		(void)hipSetDevice(sc->ctx->device);
 		(void)hipStreamSynchronize(sc->ctx->stream);
 		sc->d_models.release(); sc->d_surfaces.release(); sc->d_materials.release(); sc->d_nodes.release();
-		sc->d_refs.release(); sc->d_tris.release(); sc->d_vattr.release(); sc->d_isect.release(); sc->d_shade.release(); sc->d_visits.release(); sc->d_spaces.release(); sc->d_model_space.release();
+		sc->d_refs.release(); sc->d_tris.release(); sc->d_vattr.release(); sc->d_isect.release(); sc->d_shade.release(); sc->d_spaces.release(); sc->d_model_space.release();
 	}
 	delete sc;
 }
@@ -394,12 +387,6 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 		unsigned long long rays = 0;
 		HIP_TRY(hipMemcpy(&rays, ray_counter, 8, hipMemcpyDeviceToHost));
 		stats->rays = rays;
-#ifdef PTX_STAMP
-		unsigned long long ph[2] = {0, 0};
-		HIP_TRY(hipMemcpy(ph, ray_counter + 1, 16, hipMemcpyDeviceToHost));
-		diag_dump();
-		fprintf(stderr, "[PTX_STAMP] wave-cycles extend=%llu shade=%llu  (extend share %.1f%%)\n", ph[0], ph[1], 100.0 * ph[0] / (double)(ph[0] + ph[1]));
-#endif
 		stats->samples = (uint64_t)cfg->spp * n_pixels;
 		stats->passes = n_pass;
 		double ms = 0;

@@ -256,7 +256,7 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 		memcpy(mr.bmin, b.lo, 12);
 		memcpy(mr.bmax, b.hi, 12);
 	}
-	// distinct ray spaces (bitwise-equal inverse transforms) and the per-surface visit list
+	// distinct ray spaces (bitwise-equal inverse transforms)
 	s.spaces.clear();
 	s.model_space.assign(n_models, 0);
 	for (size_t mi = 0; mi < n_models; mi++) {
@@ -267,23 +267,6 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 		for (; k < s.spaces.size(); k++) if (!memcmp(&s.spaces[k], &sp, sizeof sp)) break;
 		if (k == s.spaces.size()) s.spaces.push_back(sp);
 		s.model_space[mi] = (uint32_t)k;
-	}
-	s.visits.assign(n_surf, VisitRec{});
-	for (size_t mi = 0; mi < n_models; mi++)
-		for (int32_t k = 0; k < s.models[mi].n_surfaces; k++) {
-			const size_t si = (size_t)s.models[mi].first_surface + k;
-			VisitRec& v = s.visits[si];
-			memcpy(v.bmin, s.surfaces[si].bmin, 12);
-			memcpy(v.bmax, s.surfaces[si].bmax, 12);
-			v.kd_root = s.surfaces[si].kd_root;
-			v.model_space = (uint32_t)mi | (s.model_space[mi] << 24);
-		}
-	{   // sort key: the surfaces a ray is most expensive to meet (leaf references ~ triangle tests + tree size)
-		std::vector<uint32_t> order(n_surf);
-		for (size_t i = 0; i < n_surf; i++) order[i] = (uint32_t)i;
-		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return s.surf_range[8 * a + 7] + s.surf_range[8 * a + 5] > s.surf_range[8 * b + 7] + s.surf_range[8 * b + 5]; });
-		order.resize(std::min<size_t>(order.size(), 8));
-		s.key_surfaces = order;
 	}
 	s.shade.assign(n_surf, ShadeRec{});
 	for (size_t mi = 0; mi < n_models; mi++)
