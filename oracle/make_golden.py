@@ -23,6 +23,44 @@ ROOT = os.path.dirname(HERE)
 HARNESS = os.path.join(HERE, "_ref", "ref_harness")
 GOLD = os.path.join(ROOT, "tests", "golden")
 CORNELL = os.path.join(ROOT, "scenes", "cornell-box", "cornell.gltf")
+JACK = os.path.join(ROOT, "scenes", "jack-of-blades", "jack-of-blades.gltf")   # derived asset, see tools/make_jack_asset.py
+
+
+def kd_stream(t, axis, split, left, right, first, count, refs):
+    """Canonical uint32 stream of a pre-order KD dump (one surface): branch = (0, axis, split bits, has_left, has_right),
+    leaf = (1, count, mesh-local triangle ids...). tests/conftest.py builds the same stream from the oracle and the product."""
+    out = []
+    sb = np.ascontiguousarray(split, np.float32).view(np.uint32)
+    for i in range(len(t)):
+        if t[i] == 1:
+            f, c = int(first[i]), int(count[i])
+            out.append(np.concatenate([[1, c], refs[f:f + c]]).astype(np.uint32))
+        else:
+            out.append(np.array([0, axis[i], sb[i], left[i] >= 0, right[i] >= 0], np.uint32))
+    return np.concatenate(out) if out else np.zeros(0, np.uint32)
+
+
+def sha(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8).copy()
+
+
+def pack_big_scene(src_dir, dst):
+    """Scene too large to commit array by array: small arrays verbatim, SHA-256 digests of the big ones."""
+    a = {os.path.basename(f)[:-4]: np.load(f) for f in sorted(glob.glob(os.path.join(src_dir, "*.npy")))}
+    out = {k: a[k] for k in ("model_xform", "model_aabb", "model_surf", "mesh_aabb", "surf_range", "materials", "material_tex",
+                             "camera", "sun", "model_names", "kd_depth")}
+    out["sha_vertices"] = sha(a["vertices"]); out["sha_triangles"] = sha(a["triangles"])
+    kd = []
+    for srow in a["surf_range"]:
+        k0, nk, r0, nr = (int(v) for v in srow[4:8])
+        sl = slice(k0, k0 + nk)
+        refs = a["kd_refs"][r0:r0 + nr]
+        kd.append(sha(kd_stream(a["kd_type"][sl], a["kd_axis"][sl], a["kd_split"][sl], a["kd_left"][sl], a["kd_right"][sl],
+                                a["kd_first"][sl] - r0, a["kd_count"][sl], refs)))
+    out["sha_kd"] = np.stack(kd)
+    np.savez_compressed(dst, **out)
+    print(f"{dst}: {os.path.getsize(dst) / 1024:.0f} KiB")
 
 
 def pack(src_dir, dst):
@@ -59,6 +97,27 @@ def main():
                 out[f"{tag}_cfg"] = np.array([W, H, spp, b], np.int32)
             np.savez_compressed(os.path.join(GOLD, "cornell_mean.npz"), **out)
             print("cornell_mean.npz written")
+        # ---- the textured, sun-lit asset (58 740 triangles, 17 textures): scene digests, material / intersection vectors, mean image
+        d = os.path.join(tmp, "jscene")
+        subprocess.check_call([HARNESS, "scene", JACK, d], env=env)
+        pack_big_scene(d, os.path.join(GOLD, "jack_scene.npz"))
+        d = os.path.join(tmp, "jvec")
+        subprocess.check_call([HARNESS, "vectors", JACK, d, "2", "192"], env=env)
+        subprocess.check_call([HARNESS, "materials", JACK, d, "5", "256"], env=env)
+        keep = ("mesh_in", "mesh_out", "mesh_idx", "world_rays", "model_out", "model_idx", "scene_out", "scene_idx", "cam_in", "cam_out",
+                "mat_in", "mat_out")
+        np.savez_compressed(os.path.join(GOLD, "jack_vectors.npz"), **{k: np.load(os.path.join(d, k + ".npy")) for k in keep})
+        print("jack_vectors.npz written")
+        if not args.no_mean:
+            out = {}
+            W, H, spp, b = 64, 36, 384, 4
+            for half, seed in (("a", "333"), ("b", "444")):
+                f = os.path.join(tmp, f"jmean_{half}.npy")
+                subprocess.check_call([HARNESS, "mean", JACK, f, str(W), str(H), str(spp), str(b), "8"], env=dict(env, ORACLE_SEED=seed))
+                out[f"b4_{half}"] = np.load(f)
+            out["b4_cfg"] = np.array([W, H, spp, b], np.int32)
+            np.savez_compressed(os.path.join(GOLD, "jack_mean.npz"), **out)
+            print("jack_mean.npz written")
         # a small deterministic PNG from renderer::render itself (single thread + fixed seed => reproducible)
         png = os.path.join(GOLD, "cornell_ref_64x64_16spp_4b.png")
         r = subprocess.check_output([HARNESS, "render", CORNELL, "64", "64", "16", "4", "1", png], env=env)

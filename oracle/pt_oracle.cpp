@@ -332,10 +332,74 @@ static mesh_hit mesh_intersect(const mesh& m, const ray& r, trav_stats* st) {
 	return {};
 }
 
-// ---------------------------------------------------------------- core/material.{hpp,cpp}
-struct material {  // factors only; texture lookups (material.cpp) are a later row of SURVEY §8f
-	v3 albedo; float opacity, roughness, metallic; v3 emissive; float ior; bool shadow_catcher;
+// ---------------------------------------------------------------- image/image.cpp, image/image_texture.cpp
+struct texture {   // 8-bit image as stb_image returns it (1-4 channels), + the sRGB flag it was first loaded with
+	int w = 0, h = 0, c = 0;
+	bool srgb = false;
+	std::vector<uint8_t> data;
 };
+struct f4v { float x, y, z, w; };
+// image::image::read — image.cpp:124-141 (LDR branch): byte / 255, sRGB decode pow(v, 2.2) on colour channels
+static inline float tex_read(const texture& t, uint32_t px, uint32_t py, uint32_t ch) {
+	uint32_t index = py * (uint32_t)t.w + px;
+	index = index * (uint32_t)t.c + ch;
+	float value = t.data[index] / 255.0F;
+	if (t.srgb && ch < 3) value = std::pow(value, 2.2F);
+	return value;
+}
+// image_texture::read_pixel — image_texture.cpp:47-62 (missing channels stay 1)
+static inline f4v tex_pixel(const texture& t, uint32_t px, uint32_t py) {
+	f4v c = {1, 1, 1, 1};
+	switch (t.c) {
+	case 4: c.w = tex_read(t, px, py, 3); [[fallthrough]];
+	case 3: c.z = tex_read(t, px, py, 2); [[fallthrough]];
+	case 2: c.y = tex_read(t, px, py, 1); [[fallthrough]];
+	case 1: c.x = tex_read(t, px, py, 0);
+	}
+	return c;
+}
+// float -> uint32 as the reference's build does it: `uvec2(floor(x), ..)` is an implicit float->unsigned conversion,
+// which g++ on x86-64 compiles to a 64-bit cvttss2si and a truncation, so negative values wrap modulo 2^32 (quirk Q3)
+static inline uint32_t f2u_wrap(float f) { return (uint32_t)(int64_t)f; }
+static inline uint32_t umod(uint32_t x, uint32_t y) { return (y + (x % y)) % y; }   // math::mod, integer branch (math.inl:189-194)
+// image_texture::sample — image_texture.cpp:21-45: bilinear, wrap by unsigned modulo
+static f4v tex_sample(const texture& t, float u, float v) {
+	const uint32_t sx = (uint32_t)t.w, sy = (uint32_t)t.h;
+	const float cx = u * sx - 0.5F, cy = (1 - v) * sy - 0.5F;
+	const uint32_t fx = f2u_wrap(std::floor(cx)), fy = f2u_wrap(std::floor(cy));
+	const uint32_t gx = f2u_wrap(std::ceil(cx)), gy = f2u_wrap(std::ceil(cy));
+	const f4v tl = tex_pixel(t, umod(fx, sx), umod(fy, sy)), tr = tex_pixel(t, umod(gx, sx), umod(fy, sy));
+	const f4v bl = tex_pixel(t, umod(fx, sx), umod(gy, sy)), br = tex_pixel(t, umod(gx, sx), umod(gy, sy));
+	const float dx = cx - std::floor(cx), dy = cy - std::floor(cy);   // math::fract
+	const f4v tt = {lerp(tl.x, tr.x, dx), lerp(tl.y, tr.y, dx), lerp(tl.z, tr.z, dx), lerp(tl.w, tr.w, dx)};
+	const f4v bb = {lerp(bl.x, br.x, dx), lerp(bl.y, br.y, dx), lerp(bl.z, br.z, dx), lerp(bl.w, br.w, dx)};
+	return {lerp(tt.x, bb.x, dy), lerp(tt.y, bb.y, dy), lerp(tt.z, bb.z, dy), lerp(tt.w, bb.w, dy)};
+}
+
+// ---------------------------------------------------------------- core/material.{hpp,cpp}
+enum { TEX_NORMAL = 0, TEX_ALBEDO, TEX_OPACITY, TEX_OCCLUSION, TEX_ROUGHNESS, TEX_METALLIC, TEX_EMISSIVE };
+struct material {
+	v3 albedo; float opacity, roughness, metallic; v3 emissive; float ior; bool shadow_catcher;
+	int tex[7] = {-1, -1, -1, -1, -1, -1, -1};   // image index per slot (material.hpp:19-26), -1 = none
+};
+struct mat_sample { v3 normal_ts, albedo, emissive; float opacity, roughness, metallic; };
+// material::get_normal / albedo / opacity / roughness / metallic / emissive — material.cpp:6-53
+static mat_sample material_eval(const material& m, const std::vector<texture>& tx, float u, float v) {
+	mat_sample o;
+	o.normal_ts = {0, 0, 1};
+	if (m.tex[TEX_NORMAL] >= 0) { f4v s = tex_sample(tx[m.tex[TEX_NORMAL]], u, v); o.normal_ts = V(s.x, s.y, s.z) * 2 - V(1, 1, 1); }
+	o.albedo = m.albedo;
+	if (m.tex[TEX_ALBEDO] >= 0) { f4v s = tex_sample(tx[m.tex[TEX_ALBEDO]], u, v); o.albedo = o.albedo * V(s.x, s.y, s.z); }
+	o.opacity = m.opacity;
+	if (m.tex[TEX_OPACITY] >= 0) o.opacity *= tex_sample(tx[m.tex[TEX_OPACITY]], u, v).w;
+	o.roughness = m.roughness;
+	if (m.tex[TEX_ROUGHNESS] >= 0) o.roughness *= tex_sample(tx[m.tex[TEX_ROUGHNESS]], u, v).y;
+	o.metallic = m.metallic;
+	if (m.tex[TEX_METALLIC] >= 0) o.metallic *= tex_sample(tx[m.tex[TEX_METALLIC]], u, v).z;
+	o.emissive = m.emissive;
+	if (m.tex[TEX_EMISSIVE] >= 0) { f4v s = tex_sample(tx[m.tex[TEX_EMISSIVE]], u, v); o.emissive = o.emissive * V(s.x, s.y, s.z); }
+	return o;
+}
 
 // ---------------------------------------------------------------- scene/model.cpp
 struct surface { mesh m; material mat; };
@@ -349,6 +413,7 @@ struct model {
 struct scene_t {
 	std::vector<model> models;      // in the order renderer::intersect visits them
 	std::vector<surface> surfaces;
+	std::vector<texture> textures;
 	xform camera; float fov, tan_half_fov;
 	bool has_sun = false; m3 sun_basis; v3 sun_energy; float sun_radius;
 };
@@ -401,12 +466,12 @@ static scene_hit scene_intersect(const scene_t& s, const ray& r, trav_stats* st)
 	return out;
 }
 
-// intersect_result::get_normal — renderer.cpp:430-435 with material::get_normal = fvec3::backward (0,0,1)
-// when there is no normal texture (material.cpp:6-11)
-static v3 shading_normal(const scene_hit& h) {
+// intersect_result::get_normal — renderer.cpp:430-435: TBN * material::get_normal(uv)
+// (= (0,0,1) without a normal texture, 2*texel-1 with one: material.cpp:6-11)
+static v3 shading_normal(const scene_hit& h, v3 normal_ts) {
 	v3 binormal = cross(h.nrm, h.tan);
 	m3 tbn = {h.tan, binormal, h.nrm};
-	return tbn * V(0, 0, 1);
+	return tbn * normal_ts;
 }
 
 // ---------------------------------------------------------------- util/rand_cone_vec.cpp:8-35
@@ -521,9 +586,10 @@ static v3 trace(trace_ctx& c, const path_key& key, uint32_t bounce, const ray& r
 	scene_hit res = scene_intersect(*c.s, r, c.st);
 	if (!res.hit) return V(c.cfg->env[0], c.cfg->env[1], c.cfg->env[2]);   // renderer.cpp:443-451, no env texture
 	const material& mt = c.s->surfaces[res.surface].mat;
-	v3 albedo = mt.albedo;
-	float opacity = mt.opacity, roughness = mt.roughness, metallic = mt.metallic;
-	v3 emissive = mt.emissive * 10;                          // renderer.cpp:462
+	const mat_sample ms = material_eval(mt, c.s->textures, res.u, res.v);   // renderer.cpp:458-462
+	v3 albedo = ms.albedo;
+	float opacity = ms.opacity, roughness = ms.roughness, metallic = ms.metallic;
+	v3 emissive = ms.emissive * 10;                          // renderer.cpp:462
 	float ior = mt.ior;
 	uint32_t depth = c.cfg->bounces - bounce;
 	f4 rnd = draws(key, depth, pass, BLOCK_SURFACE);         // x: opacity, y: lobe, z,w: BSDF sample
@@ -531,7 +597,7 @@ static v3 trace(trace_ctx& c, const path_key& key, uint32_t bounce, const ray& r
 	if (!is_approx(opacity, 1) && rnd.x > opacity)           // renderer.cpp:466-472
 		return trace(c, key, bounce, make_ray(res.pos + r.d * EPS, r.d), pass + 1);
 
-	v3 normal = shading_normal(res);
+	v3 normal = shading_normal(res, ms.normal_ts);
 	v3 outcoming = -r.d;
 	if (dot(normal, outcoming) <= 0) return V(0, 0, 0);      // renderer.cpp:478-479
 
@@ -673,6 +739,31 @@ void* ora_scene_create(int n_models, const float* model_xform /*[n][12]*/, const
 }
 void ora_scene_destroy(void* p) { delete (scene_t*)p; }
 
+// Textures: n images (8-bit, c channels, row-major as stb_image gives them) and, per surface, the image index of the
+// seven material slots (normal, albedo, opacity, occlusion, roughness, metallic, emissive) or -1.
+void ora_scene_set_textures(void* p, int n_images, const int* whc_srgb /*[n][4]*/, const uint8_t* const* data, const int* surf_tex /*[n_surf][7]*/) {
+	scene_t* s = (scene_t*)p;
+	s->textures.clear();
+	for (int i = 0; i < n_images; i++) {
+		texture t;
+		t.w = whc_srgb[4 * i]; t.h = whc_srgb[4 * i + 1]; t.c = whc_srgb[4 * i + 2]; t.srgb = whc_srgb[4 * i + 3] != 0;
+		t.data.assign(data[i], data[i] + (size_t)t.w * t.h * t.c);
+		s->textures.push_back(std::move(t));
+	}
+	for (size_t k = 0; k < s->surfaces.size(); k++)
+		for (int j = 0; j < 7; j++) s->surfaces[k].mat.tex[j] = surf_tex[7 * k + j];
+}
+// in[n][2] uv -> out[n][12]: normal_ts(3) albedo(3) opacity roughness metallic emissive(3)  (material.cpp getters)
+void ora_material_eval(void* p, int surf, size_t n, const float* uv, float* out) {
+	const scene_t& s = *(scene_t*)p;
+	for (size_t i = 0; i < n; i++) {
+		mat_sample m = material_eval(s.surfaces[surf].mat, s.textures, uv[2 * i], uv[2 * i + 1]);
+		float v[12] = {m.normal_ts.x, m.normal_ts.y, m.normal_ts.z, m.albedo.x, m.albedo.y, m.albedo.z, m.opacity, m.roughness, m.metallic,
+		               m.emissive.x, m.emissive.y, m.emissive.z};
+		memcpy(out + 12 * i, v, sizeof v);
+	}
+}
+
 // Iteration order of the reference's root-entity container (core/renderer.hpp:25,
 // std::unordered_map<std::string, shared_ptr<entity>>; filled by `entities[name] = entity`,
 // renderer.cpp:171, in scene-node order; a repeated name REPLACES the earlier entity).
@@ -766,7 +857,7 @@ void ora_scene_intersect(void* p, size_t n, const float* rays, float* out, int* 
 		float* o = out + 14 * i;
 		idx[i] = h.hit ? h.surface : -1;
 		if (!h.hit) { for (int k = 0; k < 14; k++) o[k] = 0; continue; }
-		v3 sn = shading_normal(h);
+		v3 sn = shading_normal(h, material_eval(s.surfaces[h.surface].mat, s.textures, h.u, h.v).normal_ts);
 		float v[14] = {h.pos.x, h.pos.y, h.pos.z, h.u, h.v, h.nrm.x, h.nrm.y, h.nrm.z, h.tan.x, h.tan.y, h.tan.z, sn.x, sn.y, sn.z};
 		memcpy(o, v, sizeof v);
 	}

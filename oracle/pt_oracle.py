@@ -78,6 +78,10 @@ class SceneArrays:
     material_tex: np.ndarray = None  # [n_surf, 7]    has normal/albedo/opacity/occlusion/roughness/metallic/emissive tex
     camera: np.ndarray = None        # [14]           origin3 basis9 fov tan_half_fov
     sun: np.ndarray = None           # [13] basis9 energy3 angular_radius, or None
+    images: list = field(default_factory=list)       # decoded 8-bit images [H, W, C] (as stb_image returns them)
+    image_srgb: list = field(default_factory=list)   # sRGB flag each image was FIRST loaded with (renderer.cpp:33-51 cache)
+    image_paths: list = field(default_factory=list)
+    surf_tex: np.ndarray = None      # [n_surf, 7]    image index per material slot or -1
 
 
 _NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
@@ -155,6 +159,18 @@ def load_gltf(path, camera_index=0, sun_light_index=0) -> SceneArrays:
 
     nodes = g["nodes"]
     ents = []  # dicts: name, local, parent, children, surfaces
+    tex_cache = {}   # path -> image index: get_cached_texture (renderer.cpp:33-51) caches by path, first srgb flag wins
+    out_images, out_srgb, out_paths = [], [], []
+
+    def texture(ref, srgb):
+        if ref is None:
+            return -1
+        uri = g["images"][g["textures"][ref["index"]]["source"]]["uri"]
+        path = os.path.join(base, uri).replace("%20", " ")
+        if path not in tex_cache:
+            tex_cache[path] = len(out_images)
+            out_images.append(_decode_image(path)); out_srgb.append(bool(srgb)); out_paths.append(path)
+        return tex_cache[path]
 
     def make_entity(ni, parent):
         n = nodes[ni]
@@ -175,7 +191,7 @@ def load_gltf(path, camera_index=0, sun_light_index=0) -> SceneArrays:
              "is_cam": name == cam_name, "is_sun": sun_def is not None and name == sun_def.get("name")}
         ents.append(e)
         if "mesh" in n:
-            e["surfaces"] = [(_get_mesh(g, bufs, p), _get_material(g, p)) for p in g["meshes"][n["mesh"]]["primitives"]]
+            e["surfaces"] = [(_get_mesh(g, bufs, p), _get_material(g, p, texture)) for p in g["meshes"][n["mesh"]]["primitives"]]
         for ci in n.get("children", []):
             c = make_entity(ci, e)
             e["children"].append(c)
@@ -223,7 +239,9 @@ def load_gltf(path, camera_index=0, sun_light_index=0) -> SceneArrays:
     out.vertices = np.concatenate(verts).astype(np.float32) if verts else np.zeros((0, 11), np.float32)
     out.triangles = np.concatenate(tris).astype(np.uint32) if tris else np.zeros((0, 3), np.uint32)
     out.materials = np.array(mats, dtype=np.float32).reshape(-1, 11)
-    out.material_tex = np.array(mtex, dtype=np.uint8).reshape(-1, 7)
+    out.surf_tex = np.array(mtex, dtype=np.int32).reshape(-1, 7)
+    out.material_tex = (out.surf_tex >= 0).astype(np.uint8)
+    out.images, out.image_srgb, out.image_paths = out_images, out_srgb, out_paths
     co, cb = global_xf(cam_e[-1])
     fov = f32(g["cameras"][camera_index]["perspective"]["yfov"])
     out.camera = np.array(co + cb[0] + cb[1] + cb[2] + [fov, f32(lib().ora_tan_half_fov(C.c_float(fov)))], dtype=np.float32)
@@ -264,9 +282,23 @@ def _get_mesh(g, bufs, prim):  # renderer.cpp:177-263
     return v, t
 
 
-def _get_material(g, prim):  # renderer.cpp:265-331, defaults core/material.hpp:11-17
+def _decode_image(path):
+    """8-bit pixels with the channel count stb_image reports (req_comp = 0): L=1, LA=2, RGB=3, RGBA=4, palette -> RGB(A)."""
+    from PIL import Image
+    im = Image.open(path)
+    if im.mode == "P":
+        im = im.convert("RGBA" if "transparency" in im.info else "RGB")
+    elif im.mode in ("I;16", "I"):
+        return (np.asarray(im).astype(np.uint32) >> 8).astype(np.uint8)[..., None]
+    elif im.mode not in ("L", "LA", "RGB", "RGBA"):
+        im = im.convert("RGBA")
+    a = np.asarray(im, dtype=np.uint8)
+    return np.ascontiguousarray(a if a.ndim == 3 else a[..., None])
+
+
+def _get_material(g, prim, texture):  # renderer.cpp:265-331, defaults core/material.hpp:11-17
     if "material" not in prim:
-        return [1, 1, 1, 1, 1, 1, 1, 1, 1, 1.33, 0], [0] * 7
+        return [1, 1, 1, 1, 1, 1, 1, 1, 1, 1.33, 0], [-1] * 7
     m = g["materials"][prim["material"]]
     pbr = m.get("pbrMetallicRoughness", {})
     bc = pbr.get("baseColorFactor", [1, 1, 1, 1])
@@ -275,11 +307,14 @@ def _get_material(g, prim):  # renderer.cpp:265-331, defaults core/material.hpp:
     sc = 1.0 if ("shadow" in name and "catcher" in name) else 0.0
     mat = [bc[0], bc[1], bc[2], bc[3], pbr.get("roughnessFactor", 1.0), pbr.get("metallicFactor", 1.0),
            em[0], em[1], em[2], 1.33, sc]
-    has_alb = "baseColorTexture" in pbr
-    has_mr = "metallicRoughnessTexture" in pbr
-    tex = [int("normalTexture" in m), int(has_alb), int(has_alb and m.get("alphaMode", "OPAQUE") != "OPAQUE"),
-           int("occlusionTexture" in m), int(has_mr), int(has_mr), int("emissiveTexture" in m)]
-    return mat, tex
+    # texture loads in the order of renderer.cpp:297-324 (normal, albedo[/opacity], occlusion, roughness+metallic, emissive)
+    t_n = texture(m.get("normalTexture"), False)
+    t_a = texture(pbr.get("baseColorTexture"), True)
+    t_op = t_a if (t_a >= 0 and m.get("alphaMode", "OPAQUE") != "OPAQUE") else -1
+    t_oc = texture(m.get("occlusionTexture"), False)
+    t_mr = texture(pbr.get("metallicRoughnessTexture"), False)
+    t_e = texture(m.get("emissiveTexture"), True)
+    return mat, [t_n, t_a, t_op, t_oc, t_mr, t_mr, t_e]
 
 
 # ------------------------------------------------------------------------------------------ oracle scene
@@ -297,6 +332,12 @@ class OracleScene:
                                                _p(sun) if sun is not None else None))
         self.n_models = len(a.model_xform)
         self.n_surf = len(a.surf_range)
+        if a.images:
+            self._img = [np.ascontiguousarray(im, np.uint8) for im in a.images]
+            meta = np.array([[im.shape[1], im.shape[0], im.shape[2], int(sr)] for im, sr in zip(self._img, a.image_srgb)], np.int32)
+            ptrs = (C.c_void_p * len(self._img))(*[im.ctypes.data for im in self._img])
+            st = np.ascontiguousarray(a.surf_tex, np.int32)
+            L.ora_scene_set_textures(self.h, len(self._img), _p(meta), ptrs, _p(st))
 
     def __del__(self):
         try:
@@ -319,6 +360,12 @@ class OracleScene:
                  count=np.zeros(nn, np.int32), refs=np.zeros(nr, np.uint32))
         lib().ora_kd_get(self.h, surf, *[_p(d[k]) for k in ("type", "axis", "split", "left", "right", "first", "count", "refs")])
         return d
+
+    def material_eval(self, surf, uv):
+        uv = np.ascontiguousarray(uv, np.float32)
+        out = np.zeros((len(uv), 12), np.float32)
+        lib().ora_material_eval(self.h, surf, C.c_size_t(len(uv)), _p(uv), _p(out))
+        return out
 
     def mesh_intersect(self, surf, rays):
         rays = np.ascontiguousarray(rays, np.float32)

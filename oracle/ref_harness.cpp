@@ -12,6 +12,7 @@
 // Sub-commands (all paths are given on the command line; nothing is read implicitly):
 //   scene   <gltf> <outdir>                     dump the loaded scene + KD trees as .npy
 //   vectors <gltf> <outdir> <seed> <n>          function-level known-answer vectors as .npy
+//   materials <gltf> <outdir> <seed> <n>        per surface: material::get_* (texture lookups) at n random uvs
 //   mean    <gltf> <out.npy> W H spp bounces threads   float32 mean image by calling trace()
 //   render  <gltf> W H spp bounces threads [out.png]   time renderer::render(), print JSON
 
@@ -442,6 +443,35 @@ static int cmd_vectors(const char* gltf, const std::string& dir, uint64_t seed, 
 	return 0;
 }
 
+// core::material::get_normal/albedo/opacity/roughness/metallic/emissive (core/material.cpp:6-53) over
+// image::image_texture::sample (image/image_texture.cpp:21-62) and image::image::read (image/image.cpp:124-141)
+static int cmd_materials(const char* gltf, const std::string& dir, uint64_t seed, size_t n) {
+	core::renderer r;
+	load(r, gltf);
+	std::filesystem::create_directories(dir);
+	auto models = visit_order(r);
+	pcg32 g(seed);
+	std::vector<float> in, out;
+	size_t ns = 0;
+	for (auto& m : models)
+		for (auto& s : m.model->surfaces) {
+			ns++;
+			for (size_t i = 0; i < n; i++) {
+				fvec2 uv(g.range(-1.5f, 2.5f), g.range(-1.5f, 2.5f));
+				if (i % 4 == 0) uv = fvec2(g.uni(), g.uni());
+				if (i % 31 == 0) uv = fvec2((float)(g.next() % 5) - 2.0f, (float)(g.next() % 5) - 2.0f);   // exact texel-grid edges
+				auto& mt = *s.material;
+				fvec3 nrm = mt.get_normal(uv), alb = mt.get_albedo(uv), em = mt.get_emissive(uv);
+				in.push_back(uv.x); in.push_back(uv.y);
+				push3(out, nrm); push3(out, alb); out.push_back(mt.get_opacity(uv)); out.push_back(mt.get_roughness(uv));
+				out.push_back(mt.get_metallic(uv)); push3(out, em);
+			}
+		}
+	save(dir, "mat_in", in, {ns, n, 2});
+	save(dir, "mat_out", out, {ns, n, 12});
+	return 0;
+}
+
 // float32 mean image: same pixel loop as renderer::render (renderer.cpp:354-402) but keeping the
 // float running mean instead of the 8-bit image; rows are distributed statically over threads.
 static int cmd_mean(const char* gltf, const std::string& out, uint32_t W, uint32_t H, uint32_t spp, uint32_t bounces,
@@ -504,6 +534,7 @@ int main(int argc, char** argv) {
 	try {
 		if (cmd == "scene" && argc == 4) return cmd_scene(argv[2], argv[3]);
 		if (cmd == "vectors" && argc == 6) return cmd_vectors(argv[2], argv[3], strtoull(argv[4], 0, 10), strtoull(argv[5], 0, 10));
+		if (cmd == "materials" && argc == 6) return cmd_materials(argv[2], argv[3], strtoull(argv[4], 0, 10), strtoull(argv[5], 0, 10));
 		if (cmd == "mean" && argc == 9)
 			return cmd_mean(argv[2], argv[3], atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]));
 		if (cmd == "render" && argc >= 8)
@@ -512,6 +543,6 @@ int main(int argc, char** argv) {
 		fprintf(stderr, "ref_harness: %s\n", e.what());
 		return 2;
 	}
-	fprintf(stderr, "usage: ref_harness scene|vectors|mean|render ... (see header comment)\n");
+	fprintf(stderr, "usage: ref_harness scene|vectors|materials|mean|render ... (see header comment)\n");
 	return 1;
 }

@@ -9,6 +9,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLD = os.path.join(ROOT, "tests", "golden")
 CORNELL = os.path.join(ROOT, "scenes", "cornell-box", "cornell.gltf")
+JACK = os.path.join(ROOT, "scenes", "jack-of-blades", "jack-of-blades.gltf")   # derived from the reference's asset (tools/make_jack_asset.py)
 
 
 def pytest_configure(config):
@@ -82,3 +83,59 @@ def oracle_from_dict(ora, d):
 def product_from_dict(ptx, ctx, d):
     return ptx.Scene.from_arrays(ctx, d["model_xform"], d["model_surf"], d["surf_range"], d["vertices"], d["triangles"],
                                  d["materials"], d["camera"], d.get("sun"))
+
+
+@pytest.fixture(scope="session")
+def gold_jack():
+    g = dict(np.load(os.path.join(GOLD, "jack_scene.npz")))
+    g.update(np.load(os.path.join(GOLD, "jack_vectors.npz")))
+    return g
+
+
+@pytest.fixture(scope="session")
+def jack_arrays(ora):
+    return ora.load_gltf(JACK)
+
+
+@pytest.fixture(scope="session")
+def jack_oracle(ora, jack_arrays):
+    return ora.OracleScene(jack_arrays)
+
+
+def sha_u8(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8).copy()
+
+
+def kd_stream_preorder(kd):
+    """Canonical uint32 stream (same definition as oracle/make_golden.py:kd_stream) from the oracle's pre-order dump."""
+    out = []
+    sb = np.ascontiguousarray(kd["split"], np.float32).view(np.uint32)
+    for i in range(len(kd["type"])):
+        if kd["type"][i] == 1:
+            f, c = int(kd["first"][i]), int(kd["count"][i])
+            out.append(np.concatenate([[1, c], kd["refs"][f:f + c]]).astype(np.uint32))
+        else:
+            out.append(np.array([0, kd["axis"][i], sb[i], kd["left"][i] >= 0, kd["right"][i] >= 0], np.uint32))
+    return np.concatenate(out)
+
+
+def kd_stream_packed(nodes, refs, root, tri_base):
+    """The same stream from the product's packed breadth-first nodes (iterative pre-order walk)."""
+    out = []
+    stack = [int(root)]
+    while stack:
+        i = stack.pop()
+        w0, w1 = int(nodes[i, 0]), int(nodes[i, 1])
+        kind = w1 & 3
+        if kind == 3:
+            c = w1 >> 2
+            out.append(np.concatenate([[1, c], refs[w0:w0 + c].astype(np.int64) - tri_base]).astype(np.uint32))
+            continue
+        hl, hr, first = bool(w1 & 4), bool(w1 & 8), w1 >> 4
+        out.append(np.array([0, kind, w0, hl, hr], np.uint32))
+        if hr:
+            stack.append(first + (1 if hl else 0))
+        if hl:
+            stack.append(first)
+    return np.concatenate(out)

@@ -107,3 +107,59 @@ def test_camera_rays_bit_exact(cornell_oracle, gold_vec):
 def test_tonemap_write_bytes_exact(ora, gold_vec):
     out = ora.tonemap_write(gold_vec["tone_in"])
     np.testing.assert_array_equal(out, gold_vec["tone_out"])
+
+
+# ---------------------------------------------------------------------------- textured, sun-lit asset (jack-of-blades)
+def test_jack_loader_and_trees_match_reference(jack_arrays, jack_oracle, gold_jack):
+    from conftest import kd_stream_preorder, sha_u8
+    a, g = jack_arrays, gold_jack
+    assert a.model_names == bytes(g["model_names"]).decode().split()
+    np.testing.assert_array_equal(a.model_xform, g["model_xform"])
+    np.testing.assert_array_equal(a.surf_range, g["surf_range"][:, :4])
+    np.testing.assert_array_equal(a.materials, g["materials"])
+    np.testing.assert_array_equal(a.material_tex, g["material_tex"])
+    np.testing.assert_array_equal(a.camera, g["camera"])
+    np.testing.assert_array_equal(a.sun, g["sun"])                       # KHR_lights_punctual directional light, renderer.cpp:154-160
+    np.testing.assert_array_equal(sha_u8(a.vertices), g["sha_vertices"])  # includes the mis-strided tangents (Q1) used by normal maps
+    np.testing.assert_array_equal(sha_u8(a.triangles), g["sha_triangles"])
+    mb, sb = jack_oracle.boxes()
+    np.testing.assert_array_equal(mb, g["model_aabb"])
+    np.testing.assert_array_equal(sb, g["mesh_aabb"])
+    for s in range(jack_oracle.n_surf):                                   # 58 740 triangles, 515 135 nodes, depth 26
+        kd = jack_oracle.kd(s)
+        assert len(kd["type"]) == g["surf_range"][s, 5] and len(kd["refs"]) == g["surf_range"][s, 7]
+        np.testing.assert_array_equal(sha_u8(kd_stream_preorder(kd)), g["sha_kd"][s])
+
+
+def test_jack_material_texture_lookups_bit_exact(jack_oracle, gold_jack):
+    """material::get_* over image_texture::sample: bilinear taps, unsigned-wrap of negative coordinates (Q3), sRGB pow 2.2."""
+    for s in range(jack_oracle.n_surf):
+        out = jack_oracle.material_eval(s, gold_jack["mat_in"][s])
+        np.testing.assert_array_equal(out.view(np.uint32), gold_jack["mat_out"][s].view(np.uint32))
+
+
+def test_jack_intersections_bit_exact(jack_oracle, gold_jack):
+    g = gold_jack
+    for s in range(jack_oracle.n_surf):
+        m = g["mesh_idx"][:, 1] == s
+        out, oi = jack_oracle.mesh_intersect(s, g["mesh_in"][m])
+        np.testing.assert_array_equal(oi, g["mesh_idx"][m, 0])
+        np.testing.assert_array_equal(out.view(np.uint32), g["mesh_out"][m].view(np.uint32))
+    out, oi = jack_oracle.intersect(g["world_rays"])
+    np.testing.assert_array_equal(oi, g["scene_idx"])
+    np.testing.assert_array_equal(out.view(np.uint32), g["scene_out"].view(np.uint32))   # shading normal goes through the normal maps
+    np.testing.assert_array_equal(jack_oracle.camera_rays(g["cam_in"]).view(np.uint32), g["cam_out"].view(np.uint32))
+
+
+def test_jack_mean_image_statistics(jack_oracle, ora):
+    """Sun NEE + textures + alpha in trace(): the oracle's image agrees with the reference's to within the reference's own noise."""
+    import os
+    from conftest import GOLD
+    g = dict(np.load(os.path.join(GOLD, "jack_mean.npz")))
+    W, H, spp, b = (int(v) for v in g["b4_cfg"])
+    img, _ = jack_oracle.render(ora.make_cfg(W, H, spp, b), threads=0)
+    o, ra, rb = img[..., :3], g["b4_a"], g["b4_b"]
+    rl2 = lambda x, y: np.linalg.norm(x - y) / np.linalg.norm((x + y) / 2)
+    noise = rl2(ra, rb)
+    assert rl2(o, ra) < 1.25 * noise and rl2(o, rb) < 1.25 * noise, (rl2(o, ra), rl2(o, rb), noise)
+    assert abs(o.mean() / ((ra.mean() + rb.mean()) / 2) - 1) < 0.02
