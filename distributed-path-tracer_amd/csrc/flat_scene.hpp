@@ -59,16 +59,23 @@ struct SurfaceRec {
 	uint32_t tri_base;       // global id of the mesh's triangle 0
 };
 
-// ---- material factors (core/material.hpp:11-17); emissive10 = emissive_fac * 10 (renderer.cpp:462) ----
+// ---- material factors (core/material.hpp:11-17) and texture slots ----
 struct MaterialRec {
 	float albedo[3]; float opacity;
-	float emissive10[3]; float roughness;
+	float emissive[3]; float roughness;   // emissive factor; the shader multiplies the looked-up value by 10 (renderer.cpp:462)
 	float metallic; float ior; uint32_t shadow_catcher; uint32_t tex_mask;
+	int32_t tex[7];   // texture id per slot: normal, albedo, opacity, occlusion, roughness, metallic, emissive; -1 = none
+	int32_t pad;
 };
+static_assert(sizeof(MaterialRec) == 80, "MaterialRec layout");
+
+// ---- texture: 8-bit texels exactly as the reference keeps them (image::image::data, image.cpp:124-141); the sRGB
+// decode pow(v/255, 2.2) of colour channels is a 256-entry table computed on the host with the same libm call.
+struct TexRec { uint32_t w, h, c_srgb /* channels | srgb << 8 */, offset /* first byte in the texel array */; };
 
 // ---- everything the SHADING phase needs about the surface that was hit, gathered per surface so that a
 // divergent lookup is 9 aligned 16-byte reads from one place (LDS when it fits): the owning model's
-// local->world transform and normal matrix, and the material. 144 B.
+// local->world transform and normal matrix, and the material. 176 B.
 struct ShadeRec {
 	float basis[9];   // model global basis, columns
 	float origin[3];
@@ -76,7 +83,7 @@ struct ShadeRec {
 	float pad[3];
 	MaterialRec mat;
 };
-static_assert(sizeof(ShadeRec) == 144, "ShadeRec layout");
+static_assert(sizeof(ShadeRec) == 176 && sizeof(ShadeRec) % 16 == 0, "ShadeRec layout: staged into LDS in 16-byte units");
 
 // ---- ray space: a distinct world->local transform. Models whose entity transforms are bitwise equal
 // share one, so the local ray (origin, normalised direction, reciprocal direction) is computed once per
@@ -99,7 +106,11 @@ struct FlatScene {
 	std::vector<float> vertices;         // [nv][11]
 	std::vector<uint32_t> triangles;     // [nt][3] mesh-local ids
 	std::vector<float> materials_raw;    // [ns][11]
-	std::vector<uint8_t> material_tex;   // [ns][7]
+	std::vector<uint8_t> material_tex;   // [ns][7] texture present per slot
+	std::vector<int32_t> surf_tex;       // [ns][7] texture id per slot or -1
+	std::vector<TexRec> textures;
+	std::vector<uint8_t> texels;
+	std::vector<std::string> texture_paths;
 	// derived, device-ready
 	std::vector<ModelRec> models;
 	std::vector<SurfaceRec> surfaces;
@@ -130,6 +141,7 @@ struct Error {
 	int code;
 	std::string msg;
 };
+void read_png(const std::string& path, uint32_t& W, uint32_t& H, uint32_t& C, std::vector<uint8_t>& out);
 void load_gltf(const std::string& path, uint32_t camera_index, uint32_t sun_light_index, FlatScene& out);
 
 }  // namespace ptx

@@ -254,7 +254,7 @@ Xf compose(const Xf& p, const Xf& c) {  // transform::operator*, LIB/scene/trans
 	return r;
 }
 
-struct Prim { std::vector<float> verts; std::vector<uint32_t> tris; float mat[11]; uint8_t tex[7]; };
+struct Prim { std::vector<float> verts; std::vector<uint32_t> tris; float mat[11]; int32_t tex[7]; };
 struct Entity {
 	std::string name;
 	Xf local;
@@ -272,6 +272,33 @@ struct Loader {
 	Entity* camera = nullptr;
 	Entity* sun = nullptr;
 	const JVal* lights = nullptr;
+	// get_cached_texture (renderer.cpp:33-51): one texture object per file path; the sRGB flag of the FIRST request sticks
+	std::unordered_map<std::string, int32_t> tex_by_path;
+	std::vector<TexRec> textures;
+	std::vector<uint8_t> texels;
+	std::vector<std::string> texture_paths;
+
+	int32_t texture(const JVal* ref, bool srgb) {
+		if (!ref) return -1;
+		const JVal& tex = g.root.at("textures").el((size_t)ref->at("index").i());
+		const JVal& img = g.root.at("images").el((size_t)tex.at("source").i());
+		if (!img.has("uri")) fail(E_PARSE, "glTF: image without uri (buffer-view images are not loaded by the reference either)");
+		std::string path = g.dir + "/" + uri_decode_spaces(img.at("uri").s());
+		auto it = tex_by_path.find(path);
+		if (it != tex_by_path.end()) return it->second;
+		uint32_t W, H, C;
+		std::vector<uint8_t> px;
+		read_png(path, W, H, C, px);
+		if (texels.size() + px.size() > 0xFFFFFFFFull) fail(E_PARSE, "glTF: more than 4 GiB of texels");
+		TexRec t{W, H, C | (srgb ? 256u : 0u), (uint32_t)texels.size()};
+		texels.insert(texels.end(), px.begin(), px.end());
+		while (texels.size() % 16) texels.push_back(0);
+		const int32_t id = (int32_t)textures.size();
+		textures.push_back(t);
+		texture_paths.push_back(path);
+		tex_by_path[path] = id;
+		return id;
+	}
 
 	Prim load_prim(const JVal& p) {
 		Prim out{};
@@ -302,17 +329,15 @@ struct Loader {
 
 		// material — renderer.cpp:265-331; defaults of core::material (material.hpp:11-17) when absent
 		float m[11] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1.33F, 0};
-		uint8_t tx[7] = {0, 0, 0, 0, 0, 0, 0};
+		int32_t tx[7] = {-1, -1, -1, -1, -1, -1, -1};
 		if (p.has("material")) {
 			const JVal& mat = g.root.at("materials").el((size_t)p.at("material").i());
 			float bc[4] = {1, 1, 1, 1}, em[3] = {0, 0, 0}, rough = 1, metal = 1;
-			bool alb_tex = false, mr_tex = false;
-			if (const JVal* pbr = mat.find("pbrMetallicRoughness")) {
+			const JVal* pbr = mat.find("pbrMetallicRoughness");
+			if (pbr) {
 				if (const JVal* f = pbr->find("baseColorFactor")) for (int k = 0; k < 4; k++) bc[k] = f->el(k).f();
 				if (const JVal* f = pbr->find("roughnessFactor")) rough = f->f();
 				if (const JVal* f = pbr->find("metallicFactor")) metal = f->f();
-				alb_tex = pbr->has("baseColorTexture");
-				mr_tex = pbr->has("metallicRoughnessTexture");
 			}
 			if (const JVal* f = mat.find("emissiveFactor")) for (int k = 0; k < 3; k++) em[k] = f->el(k).f();
 			std::string name = mat.has("name") ? mat.at("name").s() : "";
@@ -320,8 +345,14 @@ struct Loader {
 			float mm[11] = {bc[0], bc[1], bc[2], bc[3], rough, metal, em[0], em[1], em[2], 1.33F,
 			                (name.find("shadow") != std::string::npos && name.find("catcher") != std::string::npos) ? 1.0f : 0.0f};
 			memcpy(m, mm, sizeof m);
-			uint8_t tt[7] = {(uint8_t)mat.has("normalTexture"), (uint8_t)alb_tex, (uint8_t)(alb_tex && !opaque),
-			                 (uint8_t)mat.has("occlusionTexture"), (uint8_t)mr_tex, (uint8_t)mr_tex, (uint8_t)mat.has("emissiveTexture")};
+			// texture loads in the order of renderer.cpp:297-324: normal, base colour (also opacity unless OPAQUE), occlusion,
+			// metallic-roughness (G = roughness, B = metallic), emissive; base colour and emissive are sRGB
+			const int32_t t_n = texture(mat.find("normalTexture"), false);
+			const int32_t t_a = texture(pbr ? pbr->find("baseColorTexture") : nullptr, true);
+			const int32_t t_oc = texture(mat.find("occlusionTexture"), false);
+			const int32_t t_mr = texture(pbr ? pbr->find("metallicRoughnessTexture") : nullptr, false);
+			const int32_t t_e = texture(mat.find("emissiveTexture"), true);
+			const int32_t tt[7] = {t_n, t_a, (t_a >= 0 && !opaque) ? t_a : -1, t_oc, t_mr, t_mr, t_e};
 			memcpy(tx, tt, sizeof tx);
 		}
 		memcpy(out.mat, m, sizeof m);
@@ -433,7 +464,7 @@ void load_gltf(const std::string& path, uint32_t camera_index, uint32_t sun_ligh
 			out.vertices.insert(out.vertices.end(), p.verts.begin(), p.verts.end());
 			out.triangles.insert(out.triangles.end(), p.tris.begin(), p.tris.end());
 			out.materials_raw.insert(out.materials_raw.end(), p.mat, p.mat + 11);
-			out.material_tex.insert(out.material_tex.end(), p.tex, p.tex + 7);
+			for (int k = 0; k < 7; k++) { out.surf_tex.push_back(p.tex[k]); out.material_tex.push_back(p.tex[k] >= 0 ? 1 : 0); }
 			nv += pv; nt += pt; ns++;
 		}
 	}
@@ -453,6 +484,9 @@ void load_gltf(const std::string& path, uint32_t camera_index, uint32_t sun_ligh
 		for (int k = 0; k < 3; k++) sun13[9 + k] = col[k] * inten;  // renderer.cpp:159
 		sun13[12] = 0.004732f;                                      // sun_light::angular_radius, sun_light.hpp:10
 	}
+	out.textures = std::move(L.textures);
+	out.texels = std::move(L.texels);
+	out.texture_paths = std::move(L.texture_paths);
 	finalize_scene(out, cam13, have_sun ? sun13 : nullptr);
 }
 

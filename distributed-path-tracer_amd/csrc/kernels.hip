@@ -326,11 +326,11 @@ DEV void hit_attributes(const DevScene& S, const Geom& g, const ShadeRec& R, uin
 	out.tan = normalize(mulmv(R.nmat, mk(a1.x, a1.y, a1.z) * b0 + mk(e1.x, e1.y, e1.z) * b1 + mk(c1.x, c1.y, c1.z) * b2));
 }
 
-// intersect_result::get_normal (renderer.cpp:430-435) with material::get_normal = (0,0,1) (no normal map)
-DEV V3 shading_normal(const Surf& s) {
+// intersect_result::get_normal (renderer.cpp:430-435): TBN * material::get_normal(uv); nts = (0,0,1) without a normal map
+DEV V3 shading_normal(const Surf& s, V3 nts) {
 	V3 bin = cross(s.nrm, s.tan);
-	return {s.tan.x * 0.0f + bin.x * 0.0f + s.nrm.x * 1.0f, s.tan.y * 0.0f + bin.y * 0.0f + s.nrm.y * 1.0f,
-	        s.tan.z * 0.0f + bin.z * 0.0f + s.nrm.z * 1.0f};
+	return {s.tan.x * nts.x + bin.x * nts.y + s.nrm.x * nts.z, s.tan.y * nts.x + bin.y * nts.y + s.nrm.y * nts.z,
+	        s.tan.z * nts.x + bin.z * nts.y + s.nrm.z * nts.z};
 }
 
 // ------------------------------------------------------------------------------------ sampling / BSDF
@@ -436,13 +436,78 @@ DEV void camera_ray(const DevScene& S, const RenderParams& P, uint32_t x, uint32
 	d = normalize(mulmv(S.cam.basis, dir));
 }
 
+// ------------------------------------------------------------------------------------ textures
+// image::image::read (image/image.cpp:124-141), LDR branch: byte / 255; colour channels of an sRGB image go through
+// pow(v, 2.2) — here a 256-entry table of exactly those values.
+DEV float tex_chan(const DevScene& S, const TexRec& t, uint32_t px, uint32_t py, uint32_t ch) {
+	const uint32_t c = t.c_srgb & 255u;
+	const uint32_t b = S.texels[t.offset + (py * t.w + px) * c + ch];
+	return ((t.c_srgb >> 8) != 0 && ch < 3) ? S.srgb_lut[b] : (float)b / 255.0F;
+}
+// image_texture::read_pixel (image/image_texture.cpp:47-62): channels the image does not have stay 1
+DEV float4 tex_pixel(const DevScene& S, const TexRec& t, uint32_t px, uint32_t py) {
+	const uint32_t c = t.c_srgb & 255u;
+	float4 v = make_float4(1, 1, 1, 1);
+	v.x = tex_chan(S, t, px, py, 0);
+	if (c >= 2) v.y = tex_chan(S, t, px, py, 1);
+	if (c >= 3) v.z = tex_chan(S, t, px, py, 2);
+	if (c >= 4) v.w = tex_chan(S, t, px, py, 3);
+	return v;
+}
+// `uvec2(floor(x), ..)` in the reference is an implicit float -> unsigned conversion, compiled by g++ / x86-64 as a 64-bit
+// truncation whose low word is kept: negative coordinates wrap modulo 2^32 before the modulo by the size (quirk Q3).
+DEV uint32_t f2u_wrap(float f) { return (uint32_t)(long long)f; }
+DEV uint32_t umod(uint32_t x, uint32_t y) { return (y + (x % y)) % y; }   // math::mod, integer branch
+DEV float4 lerp4(float4 a, float4 b, float w) { return make_float4(lerpf(a.x, b.x, w), lerpf(a.y, b.y, w), lerpf(a.z, b.z, w), lerpf(a.w, b.w, w)); }
+// image_texture::sample (image/image_texture.cpp:21-45): bilinear, four taps, unsigned-modulo wrap
+DEV float4 tex_sample(const DevScene& S, int id, float u, float v) {
+	const TexRec t = S.tex[id];
+	const float cx = u * (float)t.w - 0.5F, cy = (1 - v) * (float)t.h - 0.5F;
+	const float flx = floorf(cx), fly = floorf(cy);
+	const uint32_t fx = umod(f2u_wrap(flx), t.w), fy = umod(f2u_wrap(fly), t.h);
+	const uint32_t gx = umod(f2u_wrap(ceilf(cx)), t.w), gy = umod(f2u_wrap(ceilf(cy)), t.h);
+	const float dx = cx - flx, dy = cy - fly;   // math::fract
+	const float4 top = lerp4(tex_pixel(S, t, fx, fy), tex_pixel(S, t, gx, fy), dx);
+	const float4 bot = lerp4(tex_pixel(S, t, fx, gy), tex_pixel(S, t, gx, gy), dx);
+	return lerp4(top, bot, dy);
+}
+
+struct MatEval { V3 normal_ts, albedo, emissive10; float opacity, roughness, metallic; };
+// core::material::get_normal / albedo / opacity / roughness / metallic / emissive (core/material.cpp:6-53).
+// The reference samples the base-colour texture twice (albedo, opacity) and the metallic-roughness texture twice
+// (G, B): same texture, same uv, same result — sampled once here.
+template <bool TEX>
+DEV MatEval material_eval(const DevScene& S, const MaterialRec& m, float u, float v) {
+	MatEval e;
+	e.normal_ts = mk(0, 0, 1);
+	e.albedo = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+	e.emissive10 = mk(m.emissive[0], m.emissive[1], m.emissive[2]);
+	e.opacity = m.opacity; e.roughness = m.roughness; e.metallic = m.metallic;
+	if constexpr (TEX) {
+		if (m.tex[0] >= 0) { const float4 s = tex_sample(S, m.tex[0], u, v); e.normal_ts = mk(s.x, s.y, s.z) * 2 - mk(1, 1, 1); }
+		if (m.tex[1] >= 0 || m.tex[2] >= 0) {
+			const float4 s = tex_sample(S, m.tex[1] >= 0 ? m.tex[1] : m.tex[2], u, v);
+			if (m.tex[1] >= 0) e.albedo = e.albedo * mk(s.x, s.y, s.z);
+			if (m.tex[2] >= 0) e.opacity *= (m.tex[2] == m.tex[1] || m.tex[1] < 0) ? s.w : tex_sample(S, m.tex[2], u, v).w;
+		}
+		if (m.tex[4] >= 0 || m.tex[5] >= 0) {
+			const float4 s = tex_sample(S, m.tex[4] >= 0 ? m.tex[4] : m.tex[5], u, v);
+			if (m.tex[4] >= 0) e.roughness *= s.y;
+			if (m.tex[5] >= 0) e.metallic *= (m.tex[5] == m.tex[4] || m.tex[4] < 0) ? s.z : tex_sample(S, m.tex[5], u, v).z;
+		}
+		if (m.tex[6] >= 0) { const float4 s = tex_sample(S, m.tex[6], u, v); e.emissive10 = e.emissive10 * mk(s.x, s.y, s.z); }
+	}
+	e.emissive10 = e.emissive10 * 10;   // get_emissive(uv) * 10 (renderer.cpp:462)
+	return e;
+}
+
 // ------------------------------------------------------------------------------------ one path vertex
 // renderer::trace (core/renderer.cpp:437-643) in iterative throughput form (DESIGN.md "Estimator"):
 //   L += T * (direct + emissive);  T *= clamp(brdf / max(pdf, eps), 0, 1);  next ray.
 // `h` is the closest hit of (o, d) found by the extend phase. Returns true when the path continues with
 // (o, d) updated. SUN / ALPHA select the code that needs a second traversal from inside the shading phase
 // (sun shadow rays; opacity / shadow-catcher pass-through): scenes without them get a kernel without it.
-template <bool SUN, bool ALPHA>
+template <bool SUN, bool ALPHA, bool TEX>
 DEV bool shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, const RenderParams& P, uint32_t pixel, uint32_t sample,
                       uint32_t depth, SceneHit h, V3& o, V3& d, V3& T, V3& L, uint32_t& rays, const Spill& spill) {
 	uint32_t pass = 0;
@@ -455,19 +520,20 @@ DEV bool shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, c
 		Surf sf;
 		hit_attributes(S, g, R, h.tri, h.b1, h.b2, sf);
 		const MaterialRec& mt = R.mat;
-		V3 albedo = mk(mt.albedo[0], mt.albedo[1], mt.albedo[2]);
-		float roughness = mt.roughness, metallic = mt.metallic;
+		const MatEval me = material_eval<TEX>(S, mt, sf.u, sf.v);   // renderer.cpp:458-462
+		V3 albedo = me.albedo;
+		float roughness = me.roughness, metallic = me.metallic;
 		float4 rnd = draws(P, pixel, sample, depth, pass, BLOCK_SURFACE);  // x opacity, y lobe, z/w BSDF sample
 
 		bool pass_through = false;
 		if constexpr (ALPHA) {
-			float opacity = mt.opacity;
+			float opacity = me.opacity;
 			pass_through = !(opacity == 1.0f || fabsf(opacity - 1.0f) < kEps) && rnd.x > opacity;  // renderer.cpp:466-472
 		}
 		V3 normal = mk(0, 0, 0), outcoming = -d;
 		float spec_prob = 0;
 		if (!pass_through) {
-			normal = shading_normal(sf);
+			normal = shading_normal(sf, me.normal_ts);
 			if (dot(normal, outcoming) <= 0) return false;                  // renderer.cpp:478-479: black, path ends
 			roughness = pmax(roughness, 0.05F);
 			spec_prob = fresnel_schlick(outcoming, reflect3(-outcoming, normal), mt.ior);
@@ -475,7 +541,7 @@ DEV bool shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, c
 		}
 		V3 direct_out = mk(0, 0, 0);
 		if constexpr (SUN) {
-			if (!pass_through) {                                             // renderer.cpp:498-564
+			if (S.sun.present && !pass_through) {                                             // renderer.cpp:498-564
 				float4 sr = draws(P, pixel, sample, depth, pass, BLOCK_SUN);
 				V3 din = mulmv(S.sun.basis, mk(0, 0, 1));
 				din = rand_cone_vec(sr.x, cosf(sr.y * S.sun.angular_radius), din);
@@ -512,7 +578,7 @@ DEV bool shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, c
 		}
 		V3 inc = (rnd.y < spec_prob) ? importance_specular(rnd.z, rnd.w, normal, outcoming, roughness)
 		                              : importance_diffuse(rnd.z, rnd.w, normal);
-		L = L + T * (direct_out + mk(mt.emissive10[0], mt.emissive10[1], mt.emissive10[2]));
+		L = L + T * (direct_out + me.emissive10);
 		if (!(dot(normal, inc) > 0)) return false;                           // renderer.cpp:578: no indirect term
 		float pdf;
 		V3 brdf = eval_brdf(normal, outcoming, inc, albedo, roughness, metallic, spec_prob, pdf);
@@ -533,7 +599,7 @@ DEV Staged stage_geometry(const DevScene& S, unsigned char* smem) {
 	else {
 		// [triangle records][shade records][KD nodes][leaf refs], each region a multiple of 16 B
 		uint4* dst = reinterpret_cast<uint4*>(smem);
-		const uint32_t n_tri16 = S.n_tris * 3, n_shade16 = S.n_surfaces * 9, n_node16 = (S.n_nodes + 1) / 2, n_ref16 = (S.n_refs + 3) / 4;
+		const uint32_t n_tri16 = S.n_tris * 3, n_shade16 = S.n_surfaces * (uint32_t)(sizeof(ShadeRec) / 16), n_node16 = (S.n_nodes + 1) / 2, n_ref16 = (S.n_refs + 3) / 4;
 		const uint4* src_t = reinterpret_cast<const uint4*>(S.tri_isect);
 		const uint4* src_s = reinterpret_cast<const uint4*>(S.shade);
 		const uint4* src_n = reinterpret_cast<const uint4*>(S.nodes);
@@ -558,7 +624,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 // Per wave and chunk of kChunk paths, every bounce is two sweeps over the wave's private ray stream:
 //   EXTEND: (generate or) load ray -> closest hit -> 16-byte hit record        (traversal state only in registers)
 //   SHADE : load ray + hit + path state -> BSDF, radiance, next ray -> compacted write (path state only)
-template <bool LDS, bool SUN, bool ALPHA>
+template <bool LDS, bool SUN, bool ALPHA, bool TEX>
 __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParams P, PassBuffers B, const ModelRec* __restrict__ t_models, const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
 	DevScene S = S0;
 	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;  // see struct Tables
@@ -708,7 +774,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 					h.dist = 0; h.surface = __float_as_int(hq.x); h.tri = __float_as_uint(hq.y); h.b1 = hq.z; h.b2 = hq.w;
 					const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
 					const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
-					alive = shade_vertex<SUN, ALPHA>(S, g, st.shade, P, py * P.W + px, P.sample0 + s_local, depth, h, o, d, T, L, rays,
+					alive = shade_vertex<SUN, ALPHA, TEX>(S, g, st.shade, P, py * P.W + px, P.sample0 + s_local, depth, h, o, d, T, L, rays,
 					                                 spill);
 					if (last) alive = false;  // trace(0, ..) returns black: renderer.cpp:438-439
 					if (!alive) B.sample_rad[id] = make_float4(L.x, L.y, L.z, 1.0f);
@@ -765,7 +831,11 @@ __global__ void __launch_bounds__(kBlock) k_intersect_batch(DevScene S0, Interse
 		if (A.px || A.nx || A.u) {
 			Surf sf = {};
 			V3 sn = {0, 0, 0};
-			if (hit) { hit_attributes(S, g, st.shade[h.surface], h.tri, h.b1, h.b2, sf); sn = shading_normal(sf); }
+			if (hit) {
+				const ShadeRec& R = st.shade[h.surface];
+				hit_attributes(S, g, R, h.tri, h.b1, h.b2, sf);
+				sn = shading_normal(sf, material_eval<true>(S, R.mat, sf.u, sf.v).normal_ts);
+			}
 			if (A.px) { A.px[i] = sf.pos.x; A.py[i] = sf.pos.y; A.pz[i] = sf.pos.z; }
 			if (A.nx) { A.nx[i] = sn.x; A.ny[i] = sn.y; A.nz[i] = sn.z; }
 			if (A.u) { A.u[i] = sf.u; A.v[i] = sf.v; }
@@ -803,29 +873,33 @@ static hipError_t set_lds(const void* fn, size_t bytes) {
 	return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <bool LDS, bool SUN, bool ALPHA>
+template <bool LDS, bool SUN, bool ALPHA, bool TEX>
 static hipError_t launch_pass_variant(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
 	if (LDS) {
-		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<LDS, SUN, ALPHA>), lds_bytes);
+		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<LDS, SUN, ALPHA, TEX>), lds_bytes);
 		if (e != hipSuccess) return e;
 	}
-	hipLaunchKernelGGL((k_render_pass<LDS, SUN, ALPHA>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B, S.models, S.surfaces, S.spaces, S.model_space);
+	hipLaunchKernelGGL((k_render_pass<LDS, SUN, ALPHA, TEX>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B, S.models, S.surfaces, S.spaces, S.model_space);
 	return hipGetLastError();
 }
 
+// Kernel variants: {geometry in LDS or not} x {sun shadow rays} x {opacity / shadow-catcher re-trace}; textured scenes get
+// one variant with everything compiled in (its sun code is still skipped at run time when the scene has no sun).
 hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, bool lds, size_t lds_bytes, int grid,
                               hipStream_t stream) {
 	const bool sun = S.sun.present != 0, alpha = S.any_alpha != 0;
+	if (S.any_texture) return lds ? launch_pass_variant<true, true, true, true>(S, P, B, lds_bytes, grid, stream)
+	                              : launch_pass_variant<false, true, true, true>(S, P, B, lds_bytes, grid, stream);
 	const int v = (lds ? 4 : 0) | (sun ? 2 : 0) | (alpha ? 1 : 0);
 	switch (v) {
-	case 0: return launch_pass_variant<false, false, false>(S, P, B, lds_bytes, grid, stream);
-	case 1: return launch_pass_variant<false, false, true>(S, P, B, lds_bytes, grid, stream);
-	case 2: return launch_pass_variant<false, true, false>(S, P, B, lds_bytes, grid, stream);
-	case 3: return launch_pass_variant<false, true, true>(S, P, B, lds_bytes, grid, stream);
-	case 4: return launch_pass_variant<true, false, false>(S, P, B, lds_bytes, grid, stream);
-	case 5: return launch_pass_variant<true, false, true>(S, P, B, lds_bytes, grid, stream);
-	case 6: return launch_pass_variant<true, true, false>(S, P, B, lds_bytes, grid, stream);
-	default: return launch_pass_variant<true, true, true>(S, P, B, lds_bytes, grid, stream);
+	case 0: return launch_pass_variant<false, false, false, false>(S, P, B, lds_bytes, grid, stream);
+	case 1: return launch_pass_variant<false, false, true, false>(S, P, B, lds_bytes, grid, stream);
+	case 2: return launch_pass_variant<false, true, false, false>(S, P, B, lds_bytes, grid, stream);
+	case 3: return launch_pass_variant<false, true, true, false>(S, P, B, lds_bytes, grid, stream);
+	case 4: return launch_pass_variant<true, false, false, false>(S, P, B, lds_bytes, grid, stream);
+	case 5: return launch_pass_variant<true, false, true, false>(S, P, B, lds_bytes, grid, stream);
+	case 6: return launch_pass_variant<true, true, false, false>(S, P, B, lds_bytes, grid, stream);
+	default: return launch_pass_variant<true, true, true, false>(S, P, B, lds_bytes, grid, stream);
 	}
 }
 hipError_t launch_resolve(const float4* sample_rad, float4* accum, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream) {

@@ -31,6 +31,10 @@ struct DevScene {
 	const float4* vattr;  // 2 per vertex
 	const ShadeRec* shade; // 1 per surface
 	const SpaceRec* spaces; // distinct world->local transforms
+	const TexRec* tex;       // textures
+	const uint8_t* texels;   // 8-bit texel bytes of all textures
+	const float* srgb_lut;   // [256] pow(b / 255, 2.2)
+	uint32_t any_texture;
 	const uint32_t* model_space; // per model
 	int32_t n_models;
 	uint32_t n_surfaces, n_nodes, n_refs, n_tris;

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -63,7 +64,7 @@ struct ptx_ctx {
 struct ptx_scene {
 	ptx_ctx* ctx = nullptr;
 	FlatScene host;
-	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr, d_isect, d_shade, d_spaces, d_model_space;
+	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr, d_isect, d_shade, d_tex, d_texels, d_lut, d_spaces, d_model_space;
 	DevScene dev{};
 	bool lds = false;
 	size_t lds_bytes = 0;
@@ -93,6 +94,13 @@ int upload_scene(ptx_scene* sc) {
 	HIP_TRY(up(sc->d_isect, h.tri_isect.data(), h.tri_isect.size() * 48, h.tri_isect.size() * 48));
 	HIP_TRY(up(sc->d_vattr, h.vattr.data(), h.vattr.size() * 32, h.vattr.size() * 32));
 	HIP_TRY(up(sc->d_shade, h.shade.data(), h.shade.size() * sizeof(ShadeRec), h.shade.size() * sizeof(ShadeRec)));
+	HIP_TRY(up(sc->d_tex, h.textures.data(), h.textures.size() * sizeof(TexRec), h.textures.size() * sizeof(TexRec)));
+	HIP_TRY(up(sc->d_texels, h.texels.data(), h.texels.size(), pad16(h.texels.size())));
+	{   // image::read: value = byte / 255.0F; sRGB colour channels: math::pow(value, 2.2F) (image.cpp:135-138) — same libm call, once per byte value
+		float lut[256];
+		for (int b = 0; b < 256; b++) lut[b] = std::pow(b / 255.0F, 2.2F);
+		HIP_TRY(up(sc->d_lut, lut, sizeof lut, sizeof lut));
+	}
 	HIP_TRY(up(sc->d_spaces, h.spaces.data(), h.spaces.size() * sizeof(SpaceRec), h.spaces.size() * sizeof(SpaceRec)));
 	HIP_TRY(up(sc->d_model_space, h.model_space.data(), h.model_space.size() * 4, h.model_space.size() * 4));
 	HIP_TRY(hipStreamSynchronize(c->stream));
@@ -107,6 +115,10 @@ int upload_scene(ptx_scene* sc) {
 	d.tri_isect = (const float4*)sc->d_isect.p;
 	d.shade = (const ShadeRec*)sc->d_shade.p;
 	d.spaces = (const SpaceRec*)sc->d_spaces.p;
+	d.tex = (const TexRec*)sc->d_tex.p;
+	d.texels = (const uint8_t*)sc->d_texels.p;
+	d.srgb_lut = (const float*)sc->d_lut.p;
+	d.any_texture = h.any_texture ? 1u : 0u;
 	d.model_space = (const uint32_t*)sc->d_model_space.p;
 	d.n_spaces = (uint32_t)h.spaces.size();
 	d.n_surfaces = (uint32_t)h.surfaces.size();
@@ -250,7 +262,7 @@ void ptx_scene_destroy(ptx_scene* sc) {
 		(void)hipSetDevice(sc->ctx->device);
 		(void)hipStreamSynchronize(sc->ctx->stream);
 		sc->d_models.release(); sc->d_surfaces.release(); sc->d_materials.release(); sc->d_nodes.release();
-		sc->d_refs.release(); sc->d_tris.release(); sc->d_vattr.release(); sc->d_isect.release(); sc->d_shade.release(); sc->d_spaces.release(); sc->d_model_space.release();
+		sc->d_refs.release(); sc->d_tris.release(); sc->d_vattr.release(); sc->d_isect.release(); sc->d_shade.release(); sc->d_tex.release(); sc->d_texels.release(); sc->d_lut.release(); sc->d_spaces.release(); sc->d_model_space.release();
 	}
 	delete sc;
 }
@@ -268,6 +280,7 @@ int ptx_scene_get_info(const ptx_scene* sc, ptx_scene_info* info) {
 	info->has_sun = h.sun.present;
 	info->geometry_bytes = (uint32_t)sc->lds_bytes;
 	info->lds_resident = sc->lds ? 1u : 0u;
+	info->n_textures = (uint32_t)h.textures.size();
 	return PTX_OK;
 }
 
@@ -303,6 +316,9 @@ int64_t ptx_scene_get_array(const ptx_scene* sc, ptx_array which, void* dst, siz
 	case PTX_ARR_MODEL_NAMES:
 		for (auto& n : h.model_names) names += n + "\n";
 		src = names.data(); bytes = names.size(); elem = 1; break;
+	case PTX_ARR_TEXTURES: src = h.textures.data(); bytes = h.textures.size() * sizeof(TexRec); break;
+	case PTX_ARR_TEXELS: src = h.texels.data(); bytes = h.texels.size(); elem = 1; break;
+	case PTX_ARR_SURF_TEX: src = h.surf_tex.data(); bytes = h.surf_tex.size() * 4; break;
 	default: set_err(PTX_ERR_INVALID, "unknown array id"); return -1;
 	}
 	if (dst) {
@@ -315,7 +331,6 @@ int64_t ptx_scene_get_array(const ptx_scene* sc, ptx_array which, void* dst, siz
 int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_render_stats* stats) {
 	if (!sc || !cfg || !accum) return set_err(PTX_ERR_INVALID, "ptx_render: NULL argument");
 	if (!sc->ctx) return set_err(PTX_ERR_NO_DEVICE, "ptx_render: scene was created without a GPU context (no CPU path exists)");
-	if (sc->host.any_texture) return set_err(PTX_ERR_UNSUPPORTED, "ptx_render: textured materials are not built yet");
 	if (!cfg->W || !cfg->H || !cfg->bounces) return set_err(PTX_ERR_INVALID, "ptx_render: W, H and bounces must be > 0");
 	uint32_t x0 = cfg->x0, y0 = cfg->y0, w = cfg->w, h = cfg->h;
 	if (w == 0 && h == 0) { x0 = 0; y0 = 0; w = cfg->W; h = cfg->H; }

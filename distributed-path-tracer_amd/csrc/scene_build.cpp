@@ -223,13 +223,17 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 		MaterialRec& mr = s.materials[si];
 		mr.albedo[0] = m[0]; mr.albedo[1] = m[1]; mr.albedo[2] = m[2];
 		mr.opacity = m[3]; mr.roughness = m[4]; mr.metallic = m[5];
-		for (int k = 0; k < 3; k++) mr.emissive10[k] = m[6 + k] * 10;  // get_emissive(...) * 10, renderer.cpp:462
+		for (int k = 0; k < 3; k++) mr.emissive[k] = m[6 + k];
 		mr.ior = m[9];
 		mr.shadow_catcher = m[10] != 0 ? 1u : 0u;
 		mr.tex_mask = 0;
-		if (s.material_tex.size() >= 7 * (si + 1))
-			for (int k = 0; k < 7; k++) if (s.material_tex[7 * si + k]) mr.tex_mask |= 1u << k;
+		for (int k = 0; k < 7; k++) {
+			mr.tex[k] = s.surf_tex.size() >= 7 * (si + 1) ? s.surf_tex[7 * si + k] : -1;
+			if (mr.tex[k] >= 0) mr.tex_mask |= 1u << k;
+		}
+		mr.pad = 0;
 		if (mr.tex_mask) s.any_texture = true;
+		if (mr.tex[2] >= 0) s.any_alpha = true;   // opacity comes from a texture: the pass-through branch is reachable
 		// math::is_approx(opacity, 1) (renderer.cpp:466) false, or a shadow catcher => pass-through code is needed
 		if (!(mr.opacity == 1.0f || std::fabs(mr.opacity - 1.0f) < kEps) || mr.shadow_catcher) s.any_alpha = true;
 	}

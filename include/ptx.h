@@ -31,7 +31,7 @@ typedef enum ptx_status {
 	PTX_ERR_NO_CAMERA = 4,  /* "Scene does not contain camera #i." / "Scene is missing a camera." renderer.cpp:73-74,97-98 */
 	PTX_ERR_NO_DEVICE = 5,  /* no HIP device / host-only scene used for GPU work: the product never falls back to a CPU path */
 	PTX_ERR_HIP = 6,        /* HIP runtime error (message carries hipGetErrorString) */
-	PTX_ERR_UNSUPPORTED = 7 /* feature outside the built scope (e.g. textured materials), refused rather than rendered wrong */
+	PTX_ERR_UNSUPPORTED = 7 /* feature outside the built scope (e.g. non-PNG or interlaced textures), refused rather than rendered wrong */
 } ptx_status;
 
 typedef struct ptx_ctx ptx_ctx;     /* one per GPU: device, stream, workspace */
@@ -86,6 +86,7 @@ typedef struct ptx_scene_info {
 	uint32_t has_sun;
 	uint32_t geometry_bytes;  /* nodes + refs + triangle records: what the kernels stage through LDS */
 	uint32_t lds_resident;    /* 1 when geometry_bytes fits one CU's LDS and the LDS kernels are used */
+	uint32_t n_textures;
 } ptx_scene_info;
 int ptx_scene_get_info(const ptx_scene* scene, ptx_scene_info* info);
 
@@ -104,7 +105,10 @@ typedef enum ptx_array {
 	PTX_ARR_KD_REFS = 9,      /* uint32[n_kd_refs]      (global triangle ids) */
 	PTX_ARR_CAMERA = 10,      /* float[14]: origin basis fov tan_half_fov */
 	PTX_ARR_SUN = 11,         /* float[13] or empty */
-	PTX_ARR_MODEL_NAMES = 12  /* char[]: '\n'-separated entity names in visit order */
+	PTX_ARR_MODEL_NAMES = 12, /* char[]: '\n'-separated entity names in visit order */
+	PTX_ARR_TEXTURES = 13,    /* uint32[n_textures][4]: width, height, channels | srgb << 8, byte offset into TEXELS */
+	PTX_ARR_TEXELS = 14,      /* uint8[]: 8-bit texels of all textures (rows top to bottom, as decoded) */
+	PTX_ARR_SURF_TEX = 15     /* int32[n_surfaces][7]: texture id per material slot (normal, albedo, opacity, occlusion, roughness, metallic, emissive), -1 = none */
 } ptx_array;
 int64_t ptx_scene_get_array(const ptx_scene* scene, ptx_array which, void* dst, size_t dst_bytes);
 

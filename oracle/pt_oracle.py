@@ -288,6 +288,8 @@ def _decode_image(path):
     im = Image.open(path)
     if im.mode == "P":
         im = im.convert("RGBA" if "transparency" in im.info else "RGB")
+    elif im.mode == "1":
+        im = im.convert("L")                      # 1-bit grey: stb_image scales it to 0 / 255, one channel
     elif im.mode in ("I;16", "I"):
         return (np.asarray(im).astype(np.uint32) >> 8).astype(np.uint8)[..., None]
     elif im.mode not in ("L", "LA", "RGB", "RGBA"):

@@ -194,3 +194,85 @@ def test_from_arrays_rejects_bad_input(ptx):
         ptx.Scene.from_arrays(None, bad["model_xform"], bad["model_surf"], bad["surf_range"], bad["vertices"], bad["triangles"],
                               bad["materials"], bad["camera"], bad["sun"])
     assert e.value.code == ptx.ERR_INVALID
+
+
+# ---------------------------------------------------------------------------- textured asset: loader, PNG reader, trees
+def test_jack_product_loader_matches_reference(ptx, gold_jack, jack_arrays):
+    from conftest import JACK, kd_stream_packed, sha_u8
+    s = ptx.Scene.load_gltf(None, JACK)
+    g = gold_jack
+    assert s.array(ptx.ARR_MODEL_NAMES) == bytes(g["model_names"]).decode().split()
+    np.testing.assert_array_equal(s.array(ptx.ARR_MODEL_XFORM), g["model_xform"])
+    np.testing.assert_array_equal(s.array(ptx.ARR_MATERIALS), g["materials"])
+    np.testing.assert_array_equal(s.array(ptx.ARR_CAMERA), g["camera"])
+    np.testing.assert_array_equal(s.array(ptx.ARR_SUN), g["sun"])
+    np.testing.assert_array_equal(s.array(ptx.ARR_MODEL_AABB), g["model_aabb"])
+    np.testing.assert_array_equal(s.array(ptx.ARR_MESH_AABB), g["mesh_aabb"])
+    np.testing.assert_array_equal(sha_u8(s.array(ptx.ARR_VERTICES)), g["sha_vertices"])
+    np.testing.assert_array_equal(sha_u8(s.array(ptx.ARR_TRIANGLES)), g["sha_triangles"])
+    rng, nodes, refs = s.array(ptx.ARR_SURF_RANGE), s.array(ptx.ARR_KD_NODES), s.array(ptx.ARR_KD_REFS)
+    for k in range(len(rng)):
+        assert rng[k, 5] == g["surf_range"][k, 5] and rng[k, 7] == g["surf_range"][k, 7]
+        np.testing.assert_array_equal(sha_u8(kd_stream_packed(nodes, refs, rng[k, 4], int(rng[k, 2]))), g["sha_kd"][k])
+    info = s.info()
+    assert info["n_triangles"] == 58740 and info["has_sun"] == 1 and info["lds_resident"] == 0 and info["n_textures"] == 17
+    # texture slots and decoded texels against the oracle's loader (PIL decode): same slots, same sRGB flags, same bytes
+    np.testing.assert_array_equal(s.array(ptx.ARR_SURF_TEX), jack_arrays.surf_tex)
+    np.testing.assert_array_equal((s.array(ptx.ARR_SURF_TEX) >= 0).astype(np.uint8), g["material_tex"])
+    tex, texels = s.array(ptx.ARR_TEXTURES), s.array(ptx.ARR_TEXELS)
+    for i, im in enumerate(jack_arrays.images):
+        w, h, cs, off = (int(v) for v in tex[i])
+        assert (h, w, cs & 255) == im.shape and bool(cs >> 8) == jack_arrays.image_srgb[i]
+        np.testing.assert_array_equal(texels[off:off + im.size].reshape(im.shape), im)
+
+
+def test_png_reader_against_pil(ptx, tmp_path):
+    """csrc/png_read.cpp vs PIL on every PNG flavour stb_image would accept: grey, grey+alpha, RGB, RGBA, palette (with and
+    without tRNS), 16-bit, sub-byte grey; all five filter types occur in the 'optimize' encodings."""
+    import json
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    imgs = {}
+    base = (rng.random((37, 53, 4)) * 255).astype(np.uint8)
+    base[:, :, 0] = np.linspace(0, 255, 53).astype(np.uint8)[None, :]          # smooth ramps make Sub/Up/Paeth filters win
+    base[:, :, 1] = np.linspace(0, 255, 37).astype(np.uint8)[:, None]
+    imgs["rgba"] = Image.fromarray(base, "RGBA")
+    imgs["rgb"] = Image.fromarray(base[..., :3].copy(), "RGB")
+    imgs["l"] = Image.fromarray(base[..., 1].copy(), "L")
+    imgs["la"] = Image.fromarray(base[..., [1, 3]].copy(), "LA")
+    imgs["p"] = Image.fromarray(base[..., :3].copy(), "RGB").quantize(31)
+    imgs["l16"] = Image.fromarray((base[..., 0].astype(np.uint16) * 257), "I;16")
+    imgs["l1"] = Image.fromarray((base[..., 0] > 127).astype(np.uint8) * 255, "L").convert("1")
+    gl = {"asset": {"version": "2.0"}, "scenes": [{"nodes": [0, 1]}], "cameras": [{"name": "c", "type": "perspective", "perspective": {"yfov": 0.7}}],
+          "nodes": [{"camera": 0, "name": "c"}, {"mesh": 0, "name": "m"}], "buffers": [{"uri": "b.bin", "byteLength": 132}],
+          "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 24},
+                          {"buffer": 0, "byteOffset": 60, "byteLength": 36}, {"buffer": 0, "byteOffset": 96, "byteLength": 6}],
+          "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": 3, "type": "VEC2"},
+                        {"bufferView": 2, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 3, "componentType": 5123, "count": 3, "type": "SCALAR"}],
+          "images": [], "textures": [], "materials": [], "meshes": [{"primitives": []}]}
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    blob = pos.tobytes() + np.zeros((3, 2), np.float32).tobytes() + np.tile(np.float32([0, 0, 1]), 3).tobytes() + np.uint16([0, 1, 2]).tobytes() + b"\0" * 30
+    (tmp_path / "b.bin").write_bytes(blob[:132])
+    names = sorted(imgs)
+    for i, n in enumerate(names):
+        imgs[n].save(tmp_path / f"{n}.png", optimize=True)
+        gl["images"].append({"uri": f"{n}.png"}); gl["textures"].append({"source": i})
+        gl["materials"].append({"name": n, "pbrMetallicRoughness": {"baseColorTexture": {"index": i}}})
+        gl["meshes"][0]["primitives"].append({"attributes": {"POSITION": 0, "TEXCOORD_0": 1, "NORMAL": 2}, "indices": 3, "material": i})
+    (tmp_path / "t.gltf").write_text(json.dumps(gl))
+    s = ptx.Scene.load_gltf(None, str(tmp_path / "t.gltf"))
+    tex, texels = s.array(ptx.ARR_TEXTURES), s.array(ptx.ARR_TEXELS)
+    assert len(tex) == len(names)
+    from oracle import pt_oracle as ora
+    for i, n in enumerate(names):
+        ref = ora._decode_image(str(tmp_path / f"{n}.png"))
+        w, h, cs, off = (int(v) for v in tex[i])
+        assert (h, w, cs & 255) == ref.shape, n
+        np.testing.assert_array_equal(texels[off:off + ref.size].reshape(ref.shape), ref, err_msg=n)
+    # a JPEG (or anything that is not a PNG) is refused, not mis-rendered
+    (tmp_path / "x.png").write_bytes(b"\xff\xd8\xff\xe0 not a png")
+    gl["images"][0]["uri"] = "x.png"
+    (tmp_path / "u.gltf").write_text(json.dumps(gl))
+    with pytest.raises(ptx.PtxError) as e:
+        ptx.Scene.load_gltf(None, str(tmp_path / "u.gltf"))
+    assert e.value.code == ptx.ERR_PARSE
