@@ -86,7 +86,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # BENCH_FORCE_DIST: exercise the RCCL path with one rank
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ptx = importlib.import_module("distributed-path-tracer_amd")
@@ -105,7 +106,7 @@ def main():
             collect.append(st)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -153,7 +154,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

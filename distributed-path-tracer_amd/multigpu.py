@@ -29,7 +29,7 @@ def split_samples(rank: int, world: int, spp_total: int):
 def reduce_accum(accum, dst: int = 0):
     """Sum-reduce the accumulation buffer (a torch tensor, on the GPU for nccl / on the CPU for gloo) onto rank dst."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
     return accum
 

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the bench line): throughput of the integrator on the other scene classes of BASELINE.json.
+   python tools/bench_scenes.py [--spp 32]"""
+import argparse, importlib, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+ap = argparse.ArgumentParser(); ap.add_argument("--spp", type=int, default=32); ap.add_argument("--level7", action="store_true")
+args = ap.parse_args()
+ptx = importlib.import_module("distributed-path-tracer_amd")
+proc = importlib.import_module("distributed-path-tracer_amd.procedural")
+ctx = ptx.Context(0)
+W, H, B = 1920, 1080, 8
+accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+
+
+def run(name, scene, spp):
+    scene.render(W, H, 2, B, accum=accum, want_stats=True)          # warm-up
+    accum.zero_(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    _, st = scene.render(W, H, spp, B, accum=accum, want_stats=True)
+    dt = time.perf_counter() - t
+    info = scene.info()
+    print(json.dumps({"scene": name, "triangles": info["n_triangles"], "kd_nodes": info["n_kd_nodes"], "lds_resident": info["lds_resident"],
+                      "spp": spp, "msamples_per_s": round(W * H * spp / dt / 1e6, 1), "mrays_per_s": round(st["rays"] / dt / 1e6, 1),
+                      "rays_per_sample": round(st["rays"] / st["samples"], 3), "seconds": round(dt, 3)}), flush=True)
+
+
+cornell = ptx.Scene.load_gltf(ctx, os.path.join(ROOT, "scenes/cornell-box/cornell.gltf"))
+run("cornell (config 2)", cornell, args.spp)
+run("jack-of-blades (58.7k tris, textures, sun)", ptx.Scene.load_gltf(ctx, os.path.join(ROOT, "scenes/jack-of-blades/jack-of-blades.gltf")), args.spp)
+c = {k: cornell.array(getattr(ptx, "ARR_" + k.upper())) for k in ("model_xform", "model_surf", "surf_range", "vertices", "triangles", "materials", "camera")}
+t0 = time.time()
+d = proc.cornell_with_mesh(c, level=6)
+s6 = ptx.Scene.from_arrays(ctx, d["model_xform"], d["model_surf"], d["surf_range"], d["vertices"], d["triangles"], d["materials"], d["camera"])
+print("level-6 scene build: %.1f s" % (time.time() - t0), flush=True)
+run("cornell + 81 920-triangle mesh (config 3 class)", s6, args.spp)
+if args.level7:
+    t0 = time.time()
+    d = proc.cornell_with_mesh(c, level=7)
+    s7 = ptx.Scene.from_arrays(ctx, d["model_xform"], d["model_surf"], d["surf_range"], d["vertices"], d["triangles"], d["materials"], d["camera"])
+    print("level-7 scene build: %.1f s" % (time.time() - t0), flush=True)
+    run("cornell + 327 680-triangle mesh (config 4/5 class)", s7, args.spp)
