@@ -220,7 +220,7 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, 
 		float best_t = -1.0f, bb1 = 0, bb2 = 0;
 		uint32_t best_tri = 0;
 		for (uint32_t i = 0; i < count; i++) {
-			uint32_t ti = g.refs[first_ref + i];
+			const uint32_t ti = g.refs[first_ref + i];
 			const float4 A = g.tris[3 * ti], E1 = g.tris[3 * ti + 1], E2 = g.tris[3 * ti + 2];
 			float be, ga;
 			const float t = tri_test_pre(A, E1, E2, o, d, be, ga);
@@ -636,7 +636,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 	float4* qbase = B.queues + (size_t)wave_slot * (kQueueFloat4PerWave);
 	float4* hbuf = qbase + 2u * 4u * kChunk;
 	float* hdist = reinterpret_cast<float*>(hbuf + kChunk);                 // [kChunk] world distance of the current best hit (deferral)
-	uint32_t* lists = reinterpret_cast<uint32_t*>(hbuf + kChunk) + kChunk;   // [n_models][kListCap] deferred ray indices
+	float4* lists = hbuf + kChunk + kChunk / 4u;                             // [n_models][2][kListCap]: (local origin, ray index), (local dir, -)
 	const Spill spill{B.spill + (size_t)wave_slot * (kSpillStack * 64) + lane};
 	uint32_t rays = 0;
 
@@ -656,7 +656,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 			// ---------------- EXTEND
 			// lists live in the unused part of the wave's stream area: hdist (kChunk words) + n_models lists
 			const bool defer = S.n_models <= kMaxDeferModels && S.n_models > 1 &&
-			                   (uint32_t)S.n_models * kListCap + kChunk <= (kQueueFloat4PerWave - 9u * kChunk) * 4u;
+			                   (uint32_t)S.n_models * 2u * kListCap + kChunk / 4u <= kQueueFloat4PerWave - 9u * kChunk;
 			uint32_t list_len = 0;   // lane m: entries in model m's deferred list
 			for (uint32_t base = 0; base < n_in; base += 64) {
 				const uint32_t i = base + lane;
@@ -708,7 +708,10 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 							const uint32_t len = __builtin_amdgcn_readlane(list_len, m);
 							if (enters) {
 								const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-								lists[(uint32_t)m * kListCap + len + r] = i;
+								// the deferred sweep gets the LOCAL ray: no gather of the stream entry, no second transform
+								float4* L0 = lists + (size_t)m * 2u * kListCap;
+								L0[len + r] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(i));
+								L0[kListCap + len + r] = make_float4(ld.x, ld.y, ld.z, 0.f);
 							}
 							list_len = (int)lane == m ? len + cnt : list_len;
 						}
@@ -724,23 +727,20 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 					const uint32_t len = __builtin_amdgcn_readlane(list_len, m);
 					if (len == 0) continue;
 					const ModelRec& M = S.models[m];
-					const SpaceRec& SP = S.spaces[S.model_space[m]];
+					const float4* L0 = lists + (size_t)m * 2u * kListCap;
 					for (uint32_t base = 0; base < len; base += 64) {
 						if (base + lane < len) {
-							const uint32_t i = lists[(uint32_t)m * kListCap + base + lane];
-							const float4 q0 = qin[i], q1 = qin[kChunk + i];
-							const V3 o = mk(q0.x, q0.y, q0.z), d = mk(q1.x, q1.y, q1.z);
-							const V3 lo = mulmv(SP.inv_basis, o) + mk(SP.inv_origin[0], SP.inv_origin[1], SP.inv_origin[2]);
-							const V3 ld = normalize(mulmv(SP.inv_basis, d));
+							const float4 e0 = L0[base + lane], e1 = L0[kListCap + base + lane];
+							const uint32_t i = __float_as_uint(e0.w);
+							const float bd = hdist[i];                       // current best of this ray: issued before the traversal
+							const int bs = __float_as_int(hbuf[i].x);
+							const V3 lo = mk(e0.x, e0.y, e0.z), ld = mk(e1.x, e1.y, e1.z);
 							const V3 inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
 							float wd, b1, b2; int surf; uint32_t tri;
-							if (model_traverse(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill)) {
-								const float bd = hdist[i];
-								const int bs = __float_as_int(hbuf[i].x);
-								if (wd < bd || !(bd >= 0) || (wd == bd && surf < bs)) {
-									hbuf[i] = make_float4(__int_as_float(surf), __uint_as_float(tri), b1, b2);
-									hdist[i] = wd;
-								}
+							if (model_traverse(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill) &&
+							    (wd < bd || !(bd >= 0) || (wd == bd && surf < bs))) {
+								hbuf[i] = make_float4(__int_as_float(surf), __uint_as_float(tri), b1, b2);
+								hdist[i] = wd;
 							}
 						}
 					}
