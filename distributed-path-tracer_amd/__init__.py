@@ -36,8 +36,18 @@ class PtxError(RuntimeError):
         self.code = code
 
 
+class WorkItem(C.Structure):
+    _fields_ = [("mesh_name", C.c_char_p), ("primitives", C.POINTER(C.c_int32)), ("n_primitives", C.c_uint32)]
+
+
 class LoadOpts(C.Structure):
-    _fields_ = [("camera_index", C.c_uint32), ("sun_light_index", C.c_uint32)]
+    _fields_ = [("camera_index", C.c_uint32), ("sun_light_index", C.c_uint32), ("filter_primitives", C.c_uint32),
+                ("n_work", C.c_uint32), ("work", C.POINTER(WorkItem))]
+
+
+class WorkerEvent(C.Structure):
+    _fields_ = [("num_workers", C.c_int32), ("n_work_meshes", C.c_uint32), ("worker_id", C.c_char * 64),
+                ("scene_root", C.c_char * 256), ("scene_bucket", C.c_char * 128)]
 
 
 class SceneDesc(C.Structure):
@@ -127,6 +137,7 @@ def lib():
         L.ptx_ctx_destroy.argtypes = [C.c_void_p]
         L.ptx_ctx_synchronize.argtypes = [C.c_void_p]
         L.ptx_scene_load_gltf.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(LoadOpts), C.POINTER(C.c_void_p)]
+        L.ptx_worker_event_load.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(RenderCfg), C.POINTER(WorkerEvent)]
         L.ptx_scene_from_arrays.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         L.ptx_scene_destroy.argtypes = [C.c_void_p]
         L.ptx_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
@@ -209,11 +220,41 @@ class Scene:
         _live.add(self)
 
     @classmethod
-    def load_gltf(cls, ctx, path, camera_index=0, sun_light_index=0):
+    def load_gltf(cls, ctx, path, camera_index=0, sun_light_index=0, work=None):
+        """work: None = every primitive (core::renderer::load_gltf); a dict {mesh name: [primitive indices]} = the host's
+        per-worker filter (models::work_info::work)."""
         h = C.c_void_p()
-        opts = LoadOpts(camera_index, sun_light_index)
+        opts = LoadOpts(camera_index, sun_light_index, 0, 0, None)
+        keep = []
+        if work is not None:
+            items = (WorkItem * max(len(work), 1))()
+            for k, (name, prims) in enumerate(work.items()):
+                arr = (C.c_int32 * max(len(prims), 1))(*prims)
+                keep.append(arr)
+                items[k] = WorkItem(name.encode(), arr, len(prims))
+            opts = LoadOpts(camera_index, sun_light_index, 1, len(work), items)
         _check(lib().ptx_scene_load_gltf(ctx.h if ctx else None, os.fsencode(path), C.byref(opts), C.byref(h)))
         return cls(h, ctx)
+
+    @classmethod
+    def load_event(cls, ctx, event_json, local_scene_root):
+        """The reference worker's Lambda event (events/event.json shape) -> (scene, RenderCfg, event info dict)."""
+        h, cfg, ev = C.c_void_p(), RenderCfg(), WorkerEvent()
+        _check(lib().ptx_worker_event_load(ctx.h if ctx else None, os.fsencode(event_json), os.fsencode(local_scene_root),
+                                           C.byref(h), C.byref(cfg), C.byref(ev)))
+        info = dict(num_workers=ev.num_workers, n_work_meshes=ev.n_work_meshes, worker_id=ev.worker_id.decode(),
+                    scene_root=ev.scene_root.decode(), scene_bucket=ev.scene_bucket.decode())
+        return cls(h, ctx), cfg, info
+
+    def render_cfg(self, cfg, accum=None, want_stats=True):
+        """ptx_render with a ready RenderCfg (e.g. from load_event)."""
+        W, H = cfg.W, cfg.H
+        w, h = (cfg.w, cfg.h) if cfg.w and cfg.h else (W, H)
+        if accum is None:
+            accum = np.zeros((h, w, 4), np.float32)
+        st = RenderStats()
+        _check(lib().ptx_render(self.h, C.byref(cfg), _ptr(accum), C.byref(st) if want_stats else None))
+        return accum, (dict(rays=st.rays, samples=st.samples, passes=st.passes, kernel_ms=st.kernel_ms) if want_stats else None)
 
     @classmethod
     def from_arrays(cls, ctx, model_xform, model_surf, surf_range, vertices, triangles, materials, camera, sun=None):

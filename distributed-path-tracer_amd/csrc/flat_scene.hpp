@@ -142,6 +142,23 @@ struct Error {
 	std::string msg;
 };
 void read_png(const std::string& path, uint32_t& W, uint32_t& H, uint32_t& C, std::vector<uint8_t>& out);
-void load_gltf(const std::string& path, uint32_t camera_index, uint32_t sun_light_index, FlatScene& out);
+// work: the host's `scene_info.work` primitive filter (src/models/work_info.hpp:11-15, src/scene/load_gltf.cpp:95-99):
+// when `filter` is set, only the listed primitive indices of each named mesh are loaded (a mesh that is not listed
+// loads nothing but keeps its model); when clear, every primitive is loaded (core::renderer::load_gltf).
+struct WorkFilter {
+	bool filter = false;
+	std::vector<std::pair<std::string, std::vector<int32_t>>> work;
+};
+void load_gltf(const std::string& path, uint32_t camera_index, uint32_t sun_light_index, const WorkFilter& work, FlatScene& out);
+
+// The Lambda event of the reference's worker (models::worker_info, src/models/work_info.hpp:17-32; sample:
+// path-tracer-core/events/event.json)
+struct WorkerEvent {
+	WorkFilter work;
+	std::string scene_bucket, scene_root, worker_id;
+	int32_t num_workers = 1, samples = 0, bounces = 0;
+	float X = 0, Y = 0;
+};
+void parse_worker_event(const std::string& json_path, WorkerEvent& out);
 
 }  // namespace ptx

@@ -14,7 +14,9 @@
 // The JSON reader below is a small recursive-descent parser written for this file (the reference
 // vendors cgltf; nothing of it is used here). Numbers are converted like cgltf does: (float)strtod().
 #include "flat_scene.hpp"
+#include "json_min.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -25,122 +27,6 @@
 
 namespace ptx {
 namespace {
-
-[[noreturn]] void fail(int code, const std::string& m) { throw Error{code, m}; }
-constexpr int E_IO = 2, E_PARSE = 3, E_NO_CAMERA = 4;
-
-// ------------------------------------------------------------------------------------------- JSON
-struct JVal {
-	enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
-	bool b = false;
-	double num = 0;
-	std::string str;
-	std::vector<JVal> arr;
-	std::vector<std::pair<std::string, JVal>> obj;  // insertion order is kept (attribute order matters)
-
-	const JVal* find(const char* key) const {
-		if (kind != Obj) return nullptr;
-		for (auto& kv : obj) if (kv.first == key) return &kv.second;
-		return nullptr;
-	}
-	bool has(const char* key) const { return find(key) != nullptr; }
-	const JVal& at(const char* key) const {
-		const JVal* v = find(key);
-		if (!v) fail(E_PARSE, std::string("glTF: missing key '") + key + "'");
-		return *v;
-	}
-	const JVal& el(size_t i) const {
-		if (kind != Arr || i >= arr.size()) fail(E_PARSE, "glTF: array index out of range");
-		return arr[i];
-	}
-	size_t size() const { return kind == Arr ? arr.size() : 0; }
-	float f() const { if (kind != Num) fail(E_PARSE, "glTF: number expected"); return (float)num; }
-	int64_t i() const { if (kind != Num) fail(E_PARSE, "glTF: integer expected"); return (int64_t)num; }
-	const std::string& s() const { if (kind != Str) fail(E_PARSE, "glTF: string expected"); return str; }
-};
-
-class JsonReader {
-public:
-	explicit JsonReader(const std::string& t) : p_(t.data()), end_(t.data() + t.size()) {}
-	JVal parse() {
-		JVal v = value();
-		ws();
-		if (p_ != end_) fail(E_PARSE, "JSON: trailing characters");
-		return v;
-	}
-private:
-	const char* p_;
-	const char* end_;
-	void ws() { while (p_ < end_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\t' || *p_ == '\r')) p_++; }
-	char peek() { ws(); if (p_ >= end_) fail(E_PARSE, "JSON: unexpected end"); return *p_; }
-	void expect(char c) { if (peek() != c) fail(E_PARSE, std::string("JSON: expected '") + c + "'"); p_++; }
-	JVal value() {
-		char c = peek();
-		JVal v;
-		if (c == '{') {
-			v.kind = JVal::Obj; p_++;
-			if (peek() == '}') { p_++; return v; }
-			for (;;) {
-				std::string k = string();
-				expect(':');
-				v.obj.emplace_back(std::move(k), value());
-				if (peek() == ',') { p_++; continue; }
-				expect('}');
-				return v;
-			}
-		}
-		if (c == '[') {
-			v.kind = JVal::Arr; p_++;
-			if (peek() == ']') { p_++; return v; }
-			for (;;) {
-				v.arr.push_back(value());
-				if (peek() == ',') { p_++; continue; }
-				expect(']');
-				return v;
-			}
-		}
-		if (c == '"') { v.kind = JVal::Str; v.str = string(); return v; }
-		if (!strncmp(p_, "true", 4) && end_ - p_ >= 4) { p_ += 4; v.kind = JVal::Bool; v.b = true; return v; }
-		if (!strncmp(p_, "false", 5) && end_ - p_ >= 5) { p_ += 5; v.kind = JVal::Bool; return v; }
-		if (!strncmp(p_, "null", 4) && end_ - p_ >= 4) { p_ += 4; return v; }
-		// number: hand the token to strtod (cgltf: CGLTF_ATOF on a copy of the token)
-		const char* q = p_;
-		while (q < end_ && (strchr("+-.eE", *q) || (*q >= '0' && *q <= '9'))) q++;
-		if (q == p_) fail(E_PARSE, "JSON: unexpected character");
-		std::string tok(p_, q);
-		v.kind = JVal::Num;
-		v.num = strtod(tok.c_str(), nullptr);
-		p_ = q;
-		return v;
-	}
-	std::string string() {
-		expect('"');
-		std::string out;
-		while (p_ < end_ && *p_ != '"') {
-			if (*p_ == '\\' && p_ + 1 < end_) {
-				p_++;
-				switch (*p_) {
-				case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break;
-				case 'b': out += '\b'; break; case 'f': out += '\f'; break;
-				case 'u': {  // BMP code point -> UTF-8
-					if (end_ - p_ < 5) fail(E_PARSE, "JSON: bad \\u escape");
-					unsigned cp = (unsigned)strtoul(std::string(p_ + 1, p_ + 5).c_str(), nullptr, 16);
-					p_ += 4;
-					if (cp < 0x80) out += (char)cp;
-					else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
-					else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
-					break;
-				}
-				default: out += *p_;
-				}
-				p_++;
-			} else out += *p_++;
-		}
-		if (p_ >= end_) fail(E_PARSE, "JSON: unterminated string");
-		p_++;
-		return out;
-	}
-};
 
 std::string read_file(const std::string& path, bool binary) {
 	std::ifstream f(path, binary ? std::ios::binary : std::ios::in);
@@ -272,6 +158,7 @@ struct Loader {
 	Entity* camera = nullptr;
 	Entity* sun = nullptr;
 	const JVal* lights = nullptr;
+	const WorkFilter* work = nullptr;
 	// get_cached_texture (renderer.cpp:33-51): one texture object per file path; the sRGB flag of the FIRST request sticks
 	std::unordered_map<std::string, int32_t> tex_by_path;
 	std::vector<TexRec> textures;
@@ -386,8 +273,19 @@ struct Loader {
 
 		if (n.has("mesh")) {
 			e->is_model = true;
-			const JVal& prims = g.root.at("meshes").el((size_t)n.at("mesh").i()).at("primitives");
-			for (size_t k = 0; k < prims.size(); k++) e->prims.push_back(load_prim(prims.el(k)));
+			const JVal& mesh = g.root.at("meshes").el((size_t)n.at("mesh").i());
+			const JVal& prims = mesh.at("primitives");
+			const std::vector<int32_t>* listed = nullptr;   // scene_work[mesh->name] (src/scene/load_gltf.cpp:93-99)
+			static const std::vector<int32_t> none;
+			if (work && work->filter) {
+				listed = &none;
+				const std::string mname = mesh.has("name") ? mesh.at("name").s() : std::string();
+				for (auto& kv : work->work) if (kv.first == mname) listed = &kv.second;
+			}
+			for (size_t k = 0; k < prims.size(); k++) {
+				if (listed && std::find(listed->begin(), listed->end(), (int32_t)k) == listed->end()) continue;
+				e->prims.push_back(load_prim(prims.el(k)));
+			}
 		}
 		if (e->name == camera_name) camera = e;            // pre-order; the last match wins (renderer.cpp:145-152)
 		if (want_sun && e->name == sun_name) sun = e;
@@ -408,8 +306,9 @@ struct Loader {
 
 }  // namespace
 
-void load_gltf(const std::string& path, uint32_t camera_index, uint32_t sun_light_index, FlatScene& out) {
+void load_gltf(const std::string& path, uint32_t camera_index, uint32_t sun_light_index, const WorkFilter& work, FlatScene& out) {
 	Loader L;
+	L.work = &work;
 	L.g.root = JsonReader(read_file(path, false)).parse();
 	L.g.dir = dir_of(path);
 	L.g.buffers.resize(L.g.root.has("buffers") ? L.g.root.at("buffers").size() : 0);
@@ -490,4 +389,33 @@ void load_gltf(const std::string& path, uint32_t camera_index, uint32_t sun_ligh
 	finalize_scene(out, cam13, have_sun ? sun13 : nullptr);
 }
 
+}  // namespace ptx
+
+namespace ptx {
+void parse_worker_event(const std::string& json_path, WorkerEvent& out) {
+	JVal root = JsonReader(read_file(json_path, false)).parse();
+	out = WorkerEvent{};
+	out.work.filter = true;
+	if (const JVal* si = root.find("scene_info"))
+		if (const JVal* w = si->find("work"))
+			for (auto& kv : w->obj) {
+				std::vector<int32_t> prims;
+				for (size_t k = 0; k < kv.second.size(); k++) prims.push_back((int32_t)kv.second.el(k).i());
+				out.work.work.emplace_back(kv.first, std::move(prims));
+			}
+	auto str = [&](const char* k) { const JVal* v = root.find(k); return v && v->kind == JVal::Str ? v->str : std::string(); };
+	out.scene_bucket = str("scene_bucket");
+	out.scene_root = str("scene_root");
+	out.worker_id = str("worker_id");
+	auto num = [&](const char* k) -> double {
+		const JVal* v = root.find(k);
+		if (!v || v->kind != JVal::Num) fail(E_PARSE, std::string("worker event: missing number '") + k + "'");
+		return v->num;
+	};
+	out.num_workers = (int32_t)num("num_workers");
+	out.samples = (int32_t)num("samples");
+	out.bounces = (int32_t)num("bounces");
+	out.X = (float)num("X");
+	out.Y = (float)num("Y");
+}
 }  // namespace ptx

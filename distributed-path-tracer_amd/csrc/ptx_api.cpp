@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
@@ -199,7 +200,15 @@ int ptx_scene_load_gltf(ptx_ctx* ctx, const char* path, const ptx_load_opts* opt
 	if (!path || !out) return set_err(PTX_ERR_INVALID, "ptx_scene_load_gltf: NULL argument");
 	ptx_scene* sc = new ptx_scene;
 	try {
-		load_gltf(path, opts ? opts->camera_index : 0u, opts ? opts->sun_light_index : 0u, sc->host);
+		WorkFilter wf;
+		if (opts && opts->filter_primitives) {
+			wf.filter = true;
+			for (uint32_t k = 0; k < opts->n_work; k++) {
+				const ptx_work_item& it = opts->work[k];
+				wf.work.emplace_back(it.mesh_name ? it.mesh_name : "", std::vector<int32_t>(it.primitives, it.primitives + it.n_primitives));
+			}
+		}
+		load_gltf(path, opts ? opts->camera_index : 0u, opts ? opts->sun_light_index : 0u, wf, sc->host);
 	} catch (const Error& e) {
 		delete sc;
 		return set_err(e.code, e.msg);
@@ -208,6 +217,40 @@ int ptx_scene_load_gltf(ptx_ctx* ctx, const char* path, const ptx_load_opts* opt
 		return set_err(PTX_ERR_PARSE, e.what());
 	}
 	return finish_scene(ctx, sc, out);
+}
+
+int ptx_worker_event_load(ptx_ctx* ctx, const char* event_json_path, const char* local_scene_root, ptx_scene** scene, ptx_render_cfg* cfg,
+                          ptx_worker_event* info) {
+	if (!event_json_path || !local_scene_root || !scene || !cfg) return set_err(PTX_ERR_INVALID, "ptx_worker_event_load: NULL argument");
+	ptx_scene* sc = new ptx_scene;
+	try {
+		WorkerEvent ev;
+		parse_worker_event(event_json_path, ev);
+		if (ev.samples < 0 || ev.bounces <= 0 || !(ev.X >= 1) || !(ev.Y >= 1)) throw Error{PTX_ERR_INVALID, "worker event: samples / bounces / X / Y out of range"};
+		std::string root = local_scene_root;
+		if (!root.empty() && root.back() != '/') root += '/';
+		load_gltf(root + "scene.gltf", 0u, 0u, ev.work, sc->host);   // worker::download_gltf_file: scene_root + "scene.gltf" (worker.cpp:108-112)
+		*cfg = ptx_render_cfg{};
+		cfg->W = (uint32_t)ev.X; cfg->H = (uint32_t)ev.Y;            // worker.cpp:36-38
+		cfg->spp = (uint32_t)ev.samples; cfg->bounces = (uint32_t)ev.bounces;
+		cfg->env[0] = cfg->env[1] = cfg->env[2] = 1.0f;
+		cfg->seed_lo = 0x5EEDu;
+		if (info) {
+			*info = ptx_worker_event{};
+			info->num_workers = ev.num_workers;
+			info->n_work_meshes = (uint32_t)ev.work.work.size();
+			snprintf(info->worker_id, sizeof info->worker_id, "%s", ev.worker_id.c_str());
+			snprintf(info->scene_root, sizeof info->scene_root, "%s", ev.scene_root.c_str());
+			snprintf(info->scene_bucket, sizeof info->scene_bucket, "%s", ev.scene_bucket.c_str());
+		}
+	} catch (const Error& e) {
+		delete sc;
+		return set_err(e.code, e.msg);
+	} catch (const std::exception& e) {
+		delete sc;
+		return set_err(PTX_ERR_PARSE, e.what());
+	}
+	return finish_scene(ctx, sc, scene);
 }
 
 int ptx_scene_from_arrays(ptx_ctx* ctx, const ptx_scene_desc* d, ptx_scene** out) {

@@ -54,12 +54,39 @@ int ptx_ctx_synchronize(ptx_ctx* ctx);
  * entity transforms, unpacks every primitive (with the reference's loader quirks), builds one SAH
  * KD-tree per primitive with the reference's topology (LIB/core/mesh.cpp:131-298) and flattens all of
  * it into pointer-free arrays. ctx may be NULL: the scene is then host-only (inspection, no GPU work). */
+typedef struct ptx_work_item {   /* one entry of models::work_info::work (src/models/work_info.hpp:11-15) */
+	const char* mesh_name;
+	const int32_t* primitives;
+	uint32_t n_primitives;
+} ptx_work_item;
 typedef struct ptx_load_opts {
 	uint32_t camera_index;    /* renderer.hpp:31, default 0 */
 	uint32_t sun_light_index; /* renderer.hpp:32, default 0; 0xFFFFFFFF = renderer::no_sun_light */
+	/* The host's per-worker primitive filter (distributed_scene::load_scene's scene_work, src/scene/load_gltf.cpp:93-99):
+	 * when filter_primitives != 0 only the listed primitive indices of each named mesh are loaded, and a mesh that is not
+	 * listed loads none (its model stays, empty). 0 = load everything, as core::renderer::load_gltf does. */
+	uint32_t filter_primitives;
+	uint32_t n_work;
+	const ptx_work_item* work;
 } ptx_load_opts;
 int ptx_scene_load_gltf(ptx_ctx* ctx, const char* gltf_path, const ptx_load_opts* opts /* NULL = defaults */,
                         ptx_scene** out);
+
+/* The reference worker's entry: a Lambda event (models::worker_info, src/models/work_info.hpp:17-32; sample in
+ * path-tracer-core/events/event.json) names the scene, this worker's primitives, samples, bounces and X x Y
+ * (src/main.cpp:9-25 -> processors::worker::run, worker.cpp:25-38). S3 is out of scope: `local_scene_root` is a local
+ * directory holding the event's scene_root files; `<local_scene_root>/scene.gltf` is loaded with the event's filter.
+ * cfg receives W, H, spp, bounces (+ defaults for the rest), ready for ptx_render. info may be NULL. */
+typedef struct ptx_worker_event {
+	int32_t num_workers;
+	uint32_t n_work_meshes;
+	char worker_id[64];
+	char scene_root[256];
+	char scene_bucket[128];
+} ptx_worker_event;
+struct ptx_render_cfg;
+int ptx_worker_event_load(ptx_ctx* ctx, const char* event_json_path, const char* local_scene_root, ptx_scene** scene,
+                          struct ptx_render_cfg* cfg, ptx_worker_event* info /* NULL ok */);
 
 /* Same, from caller-provided arrays (procedural scenes, or a host that did its own parsing).
  * Models are given in the order the reference's renderer::intersect would visit them. */

@@ -144,7 +144,8 @@ def _root_order(names):
     return [out[i] for i in range(k)]
 
 
-def load_gltf(path, camera_index=0, sun_light_index=0) -> SceneArrays:
+def load_gltf(path, camera_index=0, sun_light_index=0, work=None) -> SceneArrays:
+    # work: None, or {mesh name: [primitive indices]} — distributed_scene's scene_work filter (src/scene/load_gltf.cpp:93-99)
     with open(path) as fh:
         g = json.load(fh)
     base = os.path.dirname(path)
@@ -191,7 +192,10 @@ def load_gltf(path, camera_index=0, sun_light_index=0) -> SceneArrays:
              "is_cam": name == cam_name, "is_sun": sun_def is not None and name == sun_def.get("name")}
         ents.append(e)
         if "mesh" in n:
-            e["surfaces"] = [(_get_mesh(g, bufs, p), _get_material(g, p, texture)) for p in g["meshes"][n["mesh"]]["primitives"]]
+            mesh = g["meshes"][n["mesh"]]
+            listed = None if work is None else work.get(mesh.get("name", ""), [])
+            e["surfaces"] = [(_get_mesh(g, bufs, p), _get_material(g, p, texture)) for k, p in enumerate(mesh["primitives"])
+                             if listed is None or k in listed]
         for ci in n.get("children", []):
             c = make_entity(ci, e)
             e["children"].append(c)

@@ -276,3 +276,46 @@ def test_png_reader_against_pil(ptx, tmp_path):
     with pytest.raises(ptx.PtxError) as e:
         ptx.Scene.load_gltf(None, str(tmp_path / "u.gltf"))
     assert e.value.code == ptx.ERR_PARSE
+
+
+# ---------------------------------------------------------------------------- worker event front-end
+def _event(tmp_path, work, samples=5, bounces=3, X=48, Y=32):
+    import json, shutil
+    root = tmp_path / "scene-root"
+    root.mkdir()
+    shutil.copyfile(CORNELL, root / "scene.gltf")                       # the worker downloads <scene_root>scene.gltf (worker.cpp:108-112)
+    shutil.copyfile(os.path.join(os.path.dirname(CORNELL), "cornell.bin"), root / "cornell.bin")
+    ev = {"scene_info": {"work": work, "total_size": 0.05}, "scene_bucket": "distributed-path-tracer", "scene_root": "scenes/cornell-box/",
+          "worker_id": "1", "sqs_queue_arn": "", "sns_topic_arn": "", "num_workers": 1, "samples": samples, "bounces": bounces, "X": X, "Y": Y}
+    p = tmp_path / "event.json"
+    p.write_text(json.dumps(ev, indent=4))
+    return str(p), str(root)
+
+
+def test_worker_event_and_primitive_filter(ptx, ora, tmp_path):
+    """models::worker_info JSON + scene_info.work filter (host logic; the reference's HOST needs the AWS SDK and cannot be
+    built here, so this row is checked against the oracle's restatement of src/scene/load_gltf.cpp:93-99 — parity unpinned)."""
+    work = {"Cube.003": [0, 2], "Sphere": [0], "No.Such.Mesh": [0]}
+    ev, root = _event(tmp_path, work)
+    s, cfg, info = ptx.Scene.load_event(None, ev, root)
+    assert (cfg.W, cfg.H, cfg.spp, cfg.bounces) == (48, 32, 5, 3) and tuple(cfg.env) == (1.0, 1.0, 1.0)
+    assert info["worker_id"] == "1" and info["num_workers"] == 1 and info["n_work_meshes"] == 3 and info["scene_root"] == "scenes/cornell-box/"
+    a = ora.load_gltf(os.path.join(root, "scene.gltf"), work=work)
+    assert a.model_surf.tolist() == [[0, 0], [0, 0], [0, 2], [2, 0], [2, 1]]   # unlisted meshes keep an empty model
+    np.testing.assert_array_equal(s.array(ptx.ARR_MODEL_SURF), a.model_surf)
+    np.testing.assert_array_equal(s.array(ptx.ARR_SURF_RANGE)[:, :4], a.surf_range)
+    np.testing.assert_array_equal(s.array(ptx.ARR_VERTICES), a.vertices)
+    np.testing.assert_array_equal(s.array(ptx.ARR_MATERIALS), a.materials)
+    o = ora.OracleScene(a)
+    mb, sb = o.boxes()
+    np.testing.assert_array_equal(s.array(ptx.ARR_MODEL_AABB), mb)   # empty models: the cleared box (min > max), never entered
+    # the same filter through ptx_load_opts
+    s2 = ptx.Scene.load_gltf(None, os.path.join(root, "scene.gltf"), work=work)
+    np.testing.assert_array_equal(s2.array(ptx.ARR_KD_NODES), s.array(ptx.ARR_KD_NODES))
+    # no filter = core::renderer behaviour
+    assert ptx.Scene.load_gltf(None, os.path.join(root, "scene.gltf")).info()["n_surfaces"] == 7
+    bad = tmp_path / "bad.json"
+    bad.write_text('{"samples": 1}')
+    with pytest.raises(ptx.PtxError) as e:
+        ptx.Scene.load_event(None, str(bad), root)
+    assert e.value.code == ptx.ERR_PARSE
