@@ -423,6 +423,7 @@ DEV float4 draws(const RenderParams& P, uint32_t pixel, uint32_t sample, uint32_
 // scene::camera::get_ray — scene/camera.cpp:10-21 ; pixel loop of renderer::render — core/renderer.cpp:359-370
 DEV void camera_ray(const DevScene& S, const RenderParams& P, uint32_t x, uint32_t y, uint32_t sample, V3& o, V3& d) {
 	float4 j = draws(P, y * P.W + x, sample, 0, 0, BLOCK_JITTER);
+	if (P.integrator == 1u && sample == 0) j.x = j.y = 0;   // HOST worker.cpp:125-126: the first sample is not offset
 	float ndc_x = (((float)x + j.x) / (float)P.W) * 2 - 1;
 	float ndc_y = (((float)y + j.y) / (float)P.H) * 2 - 1;
 	ndc_y = -ndc_y;
@@ -590,6 +591,88 @@ DEV bool shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, c
 	}
 }
 
+// One vertex of the HOST worker's stage pipeline (PTX_INTEGRATOR_WORKER): INTERSECT's sun sample
+// (src/processors/worker/intersection_worker.cpp:22-39), DIRECT_LIGHTING's shadow query (:58-64) and SHADING
+// (shading_worker.cpp:27-199) for one worker. `L` is cloud_ray::color, `T` cloud_ray::scale; `depth` = bounce_count -
+// cloud_ray::bounce. The shadow query is issued only when its result is read (same image, fewer rays).
+template <bool TEX>
+DEV bool shade_vertex_worker(const DevScene& S, const Geom& g, const ShadeRec* shade, const RenderParams& P, uint32_t pixel, uint32_t sample,
+                             uint32_t depth, SceneHit h, V3& o, V3& d, V3& T, V3& L, uint32_t& rays, const Spill& spill) {
+	uint32_t pass = 0;
+	for (;;) {
+		if (h.surface < 0) {
+			L = L + T * mk(P.env[0], P.env[1], P.env[2]);                       // shading_worker.cpp:28-41
+			return false;
+		}
+		const ShadeRec& R = shade[h.surface];
+		Surf sf;
+		hit_attributes(S, g, R, h.tri, h.b1, h.b2, sf);
+		const MaterialRec& mt = R.mat;
+		const MatEval me = material_eval<TEX>(S, mt, sf.u, sf.v);
+		float roughness = me.roughness;
+		const float4 rnd = draws(P, pixel, sample, depth, pass, BLOCK_SURFACE);   // x opacity, y lobe, z/w BSDF sample
+		const float4 sr = draws(P, pixel, sample, depth, pass, BLOCK_SUN);        // x azimuth, y cone angle, z Russian roulette
+		L = L + T * me.emissive10;                                              // :52 — before the opacity test
+		bool pass_through = !(me.opacity == 1.0f || fabsf(me.opacity - 1.0f) < kEps) && rnd.x > me.opacity;   // :54
+		V3 normal = mk(0, 0, 0), outcoming = -d, din = mk(0, 0, 0);
+		bool lit = false;
+		if (!pass_through) {
+			normal = shading_normal(sf, me.normal_ts);
+			if (dot(normal, outcoming) <= 0) return false;                      // :68-72
+			if (S.sun.present) {
+				V3 c = mulmv(S.sun.basis, mk(0, 0, 1));
+				c = rand_cone_vec(sr.x, cosf(sr.y * S.sun.angular_radius), c);
+				din = normalize(c);                                             // ray::get_dir()
+				if (dot(normal, c) > 0 && dot(normal, din) > 0) {               // intersection_worker.cpp:33, shading_worker.cpp:80/115
+					SceneHit sh;
+					rays++;
+					lit = !scene_traverse(S, g, sf.pos + c * kEps, din, sh, spill);
+				}
+			}
+			if (mt.shadow_catcher && depth == 0) {                              // :74-105
+				if (!lit) { L = mk(0, 0, 0); return false; }
+				pass_through = true;
+			}
+		}
+		if (pass_through) {
+			o = sf.pos + d * kEps;
+			d = normalize(d);
+			pass++;
+			if (pass > 4096) return false;  // safety bound; the reference re-queues without limit
+			rays++;
+			scene_traverse(S, g, o, d, h, spill);
+			continue;
+		}
+		roughness = pmax(roughness, 0.05F);
+		float spec_prob = fresnel_schlick(outcoming, reflect3(-outcoming, normal), mt.ior);
+		spec_prob = pmax(spec_prob, me.metallic);
+		if (lit) {                                                              // :119-143
+			float pdf_unused;
+			V3 brdf = eval_brdf(normal, outcoming, din, me.albedo, roughness, me.metallic, spec_prob, pdf_unused);
+			V3 e = mk(S.sun.energy[0], S.sun.energy[1], S.sun.energy[2]);
+			float pdf = lerpf(1.0f, 1.0f, spec_prob);
+			V3 v = brdf * e / pmax(pdf, kEps);
+			L = L + T * mk(clampf(v.x, 0, e.x), clampf(v.y, 0, e.y), clampf(v.z, 0, e.z));
+		}
+		V3 inc = (rnd.y < spec_prob) ? importance_specular(rnd.z, rnd.w, normal, outcoming, roughness)
+		                              : importance_diffuse(rnd.z, rnd.w, normal);
+		if (!(dot(normal, inc) > 0)) return false;                              // :154, :196-199
+		float pdf;
+		V3 brdf = eval_brdf(normal, outcoming, inc, me.albedo, roughness, me.metallic, spec_prob, pdf);
+		float ip = pmax(pdf, kEps);
+		T = T * mk(brdf.x / ip, brdf.y / ip, brdf.z / ip);                      // :173
+		T = mk(clampf(T.x, 0, 10.0f), clampf(T.y, 0, 10.0f), clampf(T.z, 0, 10.0f));   // :175
+		o = sf.pos + inc * kEps;
+		d = normalize(inc);
+		if ((int)(P.bounces - depth) < (int)P.bounces - 2) {                    // :182-190
+			const float p = pmax(T.x, pmax(T.y, T.z));
+			if (sr.z > p) return false;
+			T = mk(T.x / p, T.y / p, T.z / p);
+		}
+		return true;
+	}
+}
+
 // ------------------------------------------------------------------------------------ LDS staging
 struct Staged { Geom g; const ShadeRec* shade; };
 
@@ -624,7 +707,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 // Per wave and chunk of kChunk paths, every bounce is two sweeps over the wave's private ray stream:
 //   EXTEND: (generate or) load ray -> closest hit -> 16-byte hit record        (traversal state only in registers)
 //   SHADE : load ray + hit + path state -> BSDF, radiance, next ray -> compacted write (path state only)
-template <bool LDS, bool SUN, bool ALPHA, bool TEX>
+template <bool LDS, bool SUN, bool ALPHA, bool TEX, bool WORKER>
 __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParams P, PassBuffers B, const ModelRec* __restrict__ t_models, const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
 	DevScene S = S0;
 	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;  // see struct Tables
@@ -774,8 +857,10 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 					h.dist = 0; h.surface = __float_as_int(hq.x); h.tri = __float_as_uint(hq.y); h.b1 = hq.z; h.b2 = hq.w;
 					const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
 					const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
-					alive = shade_vertex<SUN, ALPHA, TEX>(S, g, st.shade, P, py * P.W + px, P.sample0 + s_local, depth, h, o, d, T, L, rays,
-					                                 spill);
+					if constexpr (WORKER)
+						alive = shade_vertex_worker<TEX>(S, g, st.shade, P, py * P.W + px, P.sample0 + s_local, depth, h, o, d, T, L, rays, spill);
+					else
+						alive = shade_vertex<SUN, ALPHA, TEX>(S, g, st.shade, P, py * P.W + px, P.sample0 + s_local, depth, h, o, d, T, L, rays, spill);
 					if (last) alive = false;  // trace(0, ..) returns black: renderer.cpp:438-439
 					if (!alive) B.sample_rad[id] = make_float4(L.x, L.y, L.z, 1.0f);
 				}
@@ -873,13 +958,13 @@ static hipError_t set_lds(const void* fn, size_t bytes) {
 	return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <bool LDS, bool SUN, bool ALPHA, bool TEX>
+template <bool LDS, bool SUN, bool ALPHA, bool TEX, bool WORKER = false>
 static hipError_t launch_pass_variant(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
 	if (LDS) {
-		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<LDS, SUN, ALPHA, TEX>), lds_bytes);
+		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<LDS, SUN, ALPHA, TEX, WORKER>), lds_bytes);
 		if (e != hipSuccess) return e;
 	}
-	hipLaunchKernelGGL((k_render_pass<LDS, SUN, ALPHA, TEX>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B, S.models, S.surfaces, S.spaces, S.model_space);
+	hipLaunchKernelGGL((k_render_pass<LDS, SUN, ALPHA, TEX, WORKER>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B, S.models, S.surfaces, S.spaces, S.model_space);
 	return hipGetLastError();
 }
 
@@ -888,6 +973,12 @@ static hipError_t launch_pass_variant(const DevScene& S, const RenderParams& P, 
 hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, bool lds, size_t lds_bytes, int grid,
                               hipStream_t stream) {
 	const bool sun = S.sun.present != 0, alpha = S.any_alpha != 0;
+	if (P.integrator == 1u) {   // the HOST worker's estimator: one variant per {LDS, textures}, sun / alpha decided at run time
+		if (S.any_texture) return lds ? launch_pass_variant<true, true, true, true, true>(S, P, B, lds_bytes, grid, stream)
+		                              : launch_pass_variant<false, true, true, true, true>(S, P, B, lds_bytes, grid, stream);
+		return lds ? launch_pass_variant<true, true, true, false, true>(S, P, B, lds_bytes, grid, stream)
+		           : launch_pass_variant<false, true, true, false, true>(S, P, B, lds_bytes, grid, stream);
+	}
 	if (S.any_texture) return lds ? launch_pass_variant<true, true, true, true>(S, P, B, lds_bytes, grid, stream)
 	                              : launch_pass_variant<false, true, true, true>(S, P, B, lds_bytes, grid, stream);
 	const int v = (lds ? 4 : 0) | (sun ? 2 : 0) | (alpha ? 1 : 0);

@@ -54,6 +54,7 @@ struct RenderParams {
 	uint64_t n_paths;           // n_pixels * pass_spp
 	uint32_t seed_lo, seed_hi;
 	float env[3];
+	uint32_t integrator;        // ptx_integrator
 };
 
 struct PassBuffers {

@@ -235,6 +235,7 @@ int ptx_worker_event_load(ptx_ctx* ctx, const char* event_json_path, const char*
 		cfg->spp = (uint32_t)ev.samples; cfg->bounces = (uint32_t)ev.bounces;
 		cfg->env[0] = cfg->env[1] = cfg->env[2] = 1.0f;
 		cfg->seed_lo = 0x5EEDu;
+		cfg->integrator = PTX_INTEGRATOR_WORKER;                      // what processors::worker::run renders with
 		if (info) {
 			*info = ptx_worker_event{};
 			info->num_workers = ev.num_workers;
@@ -379,6 +380,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 	if (w == 0 && h == 0) { x0 = 0; y0 = 0; w = cfg->W; h = cfg->H; }
 	if (!w || !h || (uint64_t)x0 + w > cfg->W || (uint64_t)y0 + h > cfg->H) return set_err(PTX_ERR_INVALID, "ptx_render: tile outside the image");
 	if (cfg->bounces > 0xFFFFu) return set_err(PTX_ERR_INVALID, "ptx_render: bounces > 65535");
+	if (cfg->integrator > PTX_INTEGRATOR_WORKER) return set_err(PTX_ERR_INVALID, "ptx_render: unknown integrator");
 	ptx_ctx* c = sc->ctx;
 	std::lock_guard<std::mutex> lk(c->mu);
 	HIP_TRY(hipSetDevice(c->device));
@@ -433,6 +435,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 		P.n_paths = (uint64_t)P.pass_spp * n_pixels;
 		P.seed_lo = cfg->seed_lo; P.seed_hi = cfg->seed_hi;
 		memcpy(P.env, cfg->env, sizeof P.env);
+		P.integrator = cfg->integrator;
 		HIP_TRY(hipMemsetAsync(chunk_counter, 0, 4, c->stream));
 		if (stats) HIP_TRY(hipEventRecord(c->events[2 * p], c->stream));
 		HIP_TRY(launch_render_pass(sc->dev, P, B, sc->lds, sc->lds_bytes, grid, c->stream));

@@ -147,6 +147,15 @@ int64_t ptx_scene_get_array(const ptx_scene* scene, ptx_array which, void* dst, 
  * The fields mirror core::renderer's public fields (renderer.hpp:21-33) with the same defaults.
  * Random numbers are a counter-based Philox4x32-10 stream keyed by (seed, pixel y*W+x, sample index,
  * depth, draw), so any tiling / sample split / GPU count gives the same per-sample radiance. */
+/* Which of the reference's two estimators one sample runs.
+ * PTX_INTEGRATOR_LIB:    core::renderer::trace (LIB/core/renderer.cpp:437-643) — what `path_tracer_lib` and its example
+ *                        program render with; pinned against the compiled reference (oracle/_ref).
+ * PTX_INTEGRATOR_WORKER: the HOST worker's stage pipeline for one worker — INTERSECT -> DIRECT_LIGHTING -> SHADING ->
+ *                        ACCUMULATE (src/processors/worker/intersection_worker.cpp:10-67, shading_worker.cpp:10-201,
+ *                        worker.cpp:114-149): emissive added before the opacity test, throughput clamped to [0,10],
+ *                        Russian roulette once bounce < bounce_count-2, un-jittered sample 0, and a shadow catcher that
+ *                        is black unless its sun sample is unoccluded. HOST cannot be built here: parity unpinned. */
+typedef enum ptx_integrator { PTX_INTEGRATOR_LIB = 0, PTX_INTEGRATOR_WORKER = 1 } ptx_integrator;
 typedef struct ptx_render_cfg {
 	uint32_t W, H;          /* renderer::resolution (1920 x 1080) */
 	uint32_t spp;           /* renderer::sample_count */
@@ -156,6 +165,7 @@ typedef struct ptx_render_cfg {
 	uint32_t x0, y0, w, h;  /* tile; w = h = 0 means the whole image */
 	uint32_t sample0;       /* first sample index */
 	uint32_t spp_per_pass;  /* 0 = library default; samples of every pixel traced per kernel launch */
+	uint32_t integrator;    /* ptx_integrator */
 } ptx_render_cfg;
 typedef struct ptx_render_stats {
 	uint64_t rays;          /* closest-hit + shadow queries = renderer::intersect calls (renderer.cpp:441,509) */

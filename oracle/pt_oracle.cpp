@@ -577,6 +577,7 @@ struct render_cfg {
 	uint32_t seed_lo, seed_hi;
 	uint32_t x0, y0, w, h;      // tile
 	uint32_t sample0;           // first sample index
+	uint32_t integrator;        // 0 = renderer::trace (LIB), 1 = the HOST worker's stage pipeline (trace_worker below)
 };
 struct trace_ctx { const scene_t* s; const render_cfg* cfg; uint64_t rays = 0; trav_stats* st = nullptr; };
 
@@ -665,15 +666,135 @@ static v3 trace(trace_ctx& c, const path_key& key, uint32_t bounce, const ray& r
 	return direct_out + indirect_out + emissive;
 }
 
+// ---------------------------------------------------------------- the HOST worker's integrator ("parity unpinned")
+// src/processors/worker/{worker,intersection_worker,shading_worker,accumulation_worker}.cpp run one camera sample as a
+// message passed between stage queues: INTERSECT (closest hit + sun sample, intersection_worker.cpp:10-47) ->
+// DIRECT_LIGHTING (shadow query, :49-67) -> SHADING (shading_worker.cpp:10-201) -> ... -> ACCUMULATE. With
+// num_workers = 1 the two merge stages (intersection_worker.cpp:69-147) forward their input unchanged, so a sample is
+// the loop below. HOST links the AWS SDK and cannot be built here: this restatement is checked against the text only.
+// Differences from renderer::trace: emissive is added before the opacity test; throughput is clamped to [0,10], not
+// [0,incoming]; Russian roulette below bounce_count-2; a shadow catcher without a lit sun sample turns the sample black.
+static v3 trace_worker(trace_ctx& c, const path_key& key, ray r) {
+	const uint32_t B = c.cfg->bounces;
+	v3 color = V(0, 0, 0), scale = V(1, 1, 1);               // cloud_ray::color / ::scale (worker.cpp:140-141)
+	uint32_t bounce = B, pass = 0;                           // cloud_ray::bounce (worker.cpp:142)
+	while (bounce > 0) {                                     // shading_worker.cpp:193 / worker.cpp:143
+		const uint32_t depth = B - bounce;
+		c.rays++;
+		scene_hit res = scene_intersect(*c.s, r, c.st);      // intersect_min_result == intersect on one worker
+		if (!res.hit) {                                      // shading_worker.cpp:28-41
+			color = color + scale * V(c.cfg->env[0], c.cfg->env[1], c.cfg->env[2]);
+			break;
+		}
+		const material& mt = c.s->surfaces[res.surface].mat;
+		const mat_sample ms = material_eval(mt, c.s->textures, res.u, res.v);
+		v3 albedo = ms.albedo;
+		float opacity = ms.opacity, roughness = ms.roughness, metallic = ms.metallic;
+		v3 emissive = ms.emissive * 10;
+		float ior = mt.ior;
+		f4 rnd = draws(key, depth, pass, BLOCK_SURFACE);     // x: opacity, y: lobe, z,w: BSDF sample
+		f4 sr = draws(key, depth, pass, BLOCK_SUN);          // x: azimuth, y: cone angle, z: Russian roulette
+		v3 normal = shading_normal(res, ms.normal_ts);       // intersect_min_result's normal == result.get_normal()
+
+		// INTERSECT stage, intersection_worker.cpp:22-39: the sun sample of this vertex
+		bool have_direct = false, direct_hit = false;
+		v3 direct_incoming = V(0, 0, 0);
+		if (c.s->has_sun) {
+			v3 din = c.s->sun_basis * V(0, 0, 1);
+			din = rand_cone_vec(sr.x, std::cos(sr.y * c.s->sun_radius), din);
+			ray direct_ray = make_ray(res.pos + din * EPS, din);
+			if (dot(normal, din) > 0) {
+				have_direct = true;
+				direct_incoming = direct_ray.d;                  // ray::get_dir(): normalised
+				// the DIRECT_LIGHTING stage (:58-64) runs for every such ray; the result is only read further down
+			}
+		}
+
+		color = color + scale * emissive;                    // shading_worker.cpp:52
+
+		if (!is_approx(opacity, 1) && rnd.x > opacity) {     // :54-63 — back to INTERSECT, bounce unchanged
+			r = make_ray(res.pos + r.d * EPS, r.d);
+			pass++;
+			continue;
+		}
+		v3 outcoming = -r.d;
+		if (dot(normal, outcoming) <= 0) break;              // :68-72
+		if (have_direct) {
+			c.rays++;
+			direct_hit = scene_intersect(*c.s, make_ray(res.pos + direct_incoming * EPS, direct_incoming), c.st).hit;
+		}
+		const bool lit = have_direct && dot(normal, direct_incoming) > 0 && !direct_hit;   // :77-87, :112-118
+		if (mt.shadow_catcher && bounce == B) {              // :74-105
+			if (!lit) { color = V(0, 0, 0); break; }
+			r = make_ray(res.pos + r.d * EPS, r.d);
+			pass++;
+			continue;
+		}
+		roughness = fmax2(roughness, 0.05F);
+		float specular_probability = fresnel(outcoming, reflect(-outcoming, normal), ior);
+		specular_probability = fmax2(specular_probability, metallic);
+		bool specular_sample = rnd.y < specular_probability;
+		if (lit) {                                           // :119-143
+			float diffuse_pdf = pdf_diffuse(normal, direct_incoming);
+			v3 diffuse_brdf = diffuse_pdf * albedo;
+			float specular_pdf = pdf_specular(normal, outcoming, direct_incoming, roughness);
+			v3 specular_brdf = V(specular_pdf, specular_pdf, specular_pdf);
+			v3 fr = vlerp(V(0.04F, 0.04F, 0.04F), albedo, metallic);
+			{
+				v3 halfway = normalize(outcoming + direct_incoming);
+				float cos_theta = dot(outcoming, halfway);
+				fr = vlerp(fr, V(1, 1, 1), pow_fi(1 - cos_theta, 5));
+			}
+			diffuse_brdf = vlerp(diffuse_brdf, V(0, 0, 0), metallic);
+			v3 brdf = vlerp(diffuse_brdf, specular_brdf, fr);
+			float pdf = lerp(1, 1, specular_probability);
+			v3 direct_in = c.s->sun_energy;
+			v3 direct_out = brdf * direct_in / fmax2(pdf, EPS);
+			direct_out = {clampf(direct_out.x, 0, direct_in.x), clampf(direct_out.y, 0, direct_in.y),
+			              clampf(direct_out.z, 0, direct_in.z)};
+			color = color + scale * direct_out;
+		}
+		v3 indirect_incoming = specular_sample ? importance_specular(rnd.z, rnd.w, normal, outcoming, roughness)
+		                                       : importance_diffuse(rnd.z, rnd.w, normal);
+		if (!(dot(normal, indirect_incoming) > 0)) break;    // :154, :196-199
+		float diffuse_pdf = pdf_diffuse(normal, indirect_incoming);
+		v3 diffuse_brdf = diffuse_pdf * albedo;
+		float specular_pdf = pdf_specular(normal, outcoming, indirect_incoming, roughness);
+		v3 specular_brdf = V(specular_pdf, specular_pdf, specular_pdf);
+		v3 fr = vlerp(V(0.04F, 0.04F, 0.04F), albedo, metallic);
+		{
+			v3 halfway = normalize(outcoming + indirect_incoming);
+			float cos_theta = dot(outcoming, halfway);
+			fr = vlerp(fr, V(1, 1, 1), pow_fi(1 - cos_theta, 5));
+		}
+		diffuse_brdf = vlerp(diffuse_brdf, V(0, 0, 0), metallic);
+		v3 brdf = vlerp(diffuse_brdf, specular_brdf, fr);
+		float pdf = lerp(diffuse_pdf, specular_pdf, specular_probability);
+		scale = scale * (brdf / fmax2(pdf, EPS));            // :173
+		scale = {clampf(scale.x, 0, 10.0f), clampf(scale.y, 0, 10.0f), clampf(scale.z, 0, 10.0f)};   // :175
+		r = make_ray(res.pos + indirect_incoming * EPS, indirect_incoming);
+		if ((int)bounce < (int)B - 2) {                      // :182-190 (uint8_t operands promote to int)
+			float p = fmax2(scale.x, fmax2(scale.y, scale.z));
+			if (sr.z > p) break;
+			scale = scale / p;
+		}
+		bounce -= 1;
+		pass = 0;
+	}
+	return color;
+}
+
 // One camera sample: jitter -> NDC -> camera ray -> trace. renderer.cpp:359-371
 static v3 sample_pixel(trace_ctx& c, uint32_t x, uint32_t y, uint32_t s) {
 	const render_cfg& cfg = *c.cfg;
 	path_key key = {y * cfg.W + x, s, cfg.seed_lo, cfg.seed_hi};
 	f4 j = draws(key, 0, 0, BLOCK_JITTER);
+	if (cfg.integrator == 1 && s == 0) j.x = j.y = 0;       // worker.cpp:125-126: the first sample is not offset
 	float ndc_x = (((float)x + j.x) / (float)cfg.W) * 2 - 1;
 	float ndc_y = (((float)y + j.y) / (float)cfg.H) * 2 - 1;
 	ndc_y = -ndc_y;
 	float ratio = (float)cfg.W / (float)cfg.H;
+	if (cfg.integrator == 1) return trace_worker(c, key, camera_ray(*c.s, ndc_x, ndc_y, ratio));
 	return trace(c, key, cfg.bounces, camera_ray(*c.s, ndc_x, ndc_y, ratio), 0);
 }
 
@@ -916,6 +1037,7 @@ void ora_primary_rays(void* p, const render_cfg* cfg, uint32_t sample, float* ou
 			uint32_t x = cfg->x0 + xx, y = cfg->y0 + yy;
 			path_key key = {y * cfg->W + x, sample, cfg->seed_lo, cfg->seed_hi};
 			f4 j = draws(key, 0, 0, BLOCK_JITTER);
+			if (cfg->integrator == 1 && sample == 0) j.x = j.y = 0;
 			float ndc_x = (((float)x + j.x) / (float)cfg->W) * 2 - 1;
 			float ndc_y = -((((float)y + j.y) / (float)cfg->H) * 2 - 1);
 			ray r = camera_ray(s, ndc_x, ndc_y, (float)cfg->W / (float)cfg->H);

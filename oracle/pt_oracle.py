@@ -54,13 +54,13 @@ class RenderCfg(C.Structure):
     _fields_ = [("W", C.c_uint32), ("H", C.c_uint32), ("spp", C.c_uint32), ("bounces", C.c_uint32),
                 ("env", C.c_float * 3), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
                 ("x0", C.c_uint32), ("y0", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32),
-                ("sample0", C.c_uint32)]
+                ("sample0", C.c_uint32), ("integrator", C.c_uint32)]
 
 
-def make_cfg(W, H, spp, bounces, env=(1.0, 1.0, 1.0), seed=0x5EED, tile=None, sample0=0):
+def make_cfg(W, H, spp, bounces, env=(1.0, 1.0, 1.0), seed=0x5EED, tile=None, sample0=0, integrator=0):
     x0, y0, w, h = tile if tile else (0, 0, W, H)
     c = RenderCfg(W, H, spp, bounces, (C.c_float * 3)(*env), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF,
-                  x0, y0, w, h, sample0)
+                  x0, y0, w, h, sample0, integrator)
     return c
 
 

@@ -350,7 +350,8 @@ def test_worker_event_render_and_cli(ptx, ctx, ora, tmp_path):
     s, cfg, info = ptx.Scene.load_event(ctx, ev, root)
     accum, st = s.render_cfg(cfg)
     o = ora.OracleScene(ora.load_gltf(os.path.join(root, "scene.gltf"), work=work))
-    mean, _ = o.render(ora.make_cfg(96, 64, 6, 4), threads=0)
+    assert cfg.integrator == ptx.INTEGRATOR_WORKER      # the event is the worker's input: its estimator, not renderer::trace
+    mean, _ = o.render(ora.make_cfg(96, 64, 6, 4, integrator=1), threads=0)
     assert ora.psnr8(ctx.tonemap_encode(accum, 96, 64, 6), ora.tonemap_write(mean)) >= 40.0
     out = str(tmp_path / "ev.png")
     r = subprocess.run([os.path.join(ROOT, "distributed-path-tracer_amd", "ptx_render_cli"), "--event", ev, root, out], capture_output=True, text=True, timeout=300)
