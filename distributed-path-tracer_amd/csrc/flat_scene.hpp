@@ -35,7 +35,9 @@ struct TriRec { float ax, ay, az; uint32_t ia; float bx, by, bz; uint32_t ib; fl
 // a.xyz, c3 | e1 = a-b | e2 = a-c, with c3 = e1.y*e2.z - e2.y*e1.z — the ray-independent sub-terms of the
 // reference's Cramer solve (triangle.cpp:136-147: m.x = a-b, m.y = a-c, c3), computed once on the host with
 // the same float operations (so the same bits) instead of once per ray-triangle test.
-struct TriIsect { float ax, ay, az, c3; float e1x, e1y, e1z, p0; float e2x, e2y, e2z, p1; };
+// Ordered for packed-fp32 math (v_pk_mul_f32 / v_pk_add_f32 take even-aligned register pairs): every pair the solve
+// multiplies lane-wise sits in one 8-byte slot, so the three LDS / global reads deliver it ready to use.
+struct TriIsect { float e2y, e1z, e2z, e1y; float e1x, e2x, ay, az; float ax, c3, p0, p1; };
 
 // ---- vertex attributes: 2 x float4 (32 B) — normal.xyz, u | tangent.xyz, v ----
 struct VertAttr { float nx, ny, nz, u, tx, ty, tz, v; };

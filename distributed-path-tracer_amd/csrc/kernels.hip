@@ -62,7 +62,7 @@ DEV V3 mulmv(const float* m, V3 v) {
 struct Geom {
 	const uint2* nodes;
 	const uint32_t* refs;
-	const float4* tris;   // TriIsect records: (a, c3) (e1) (e2)
+	const float4* tris;   // TriIsect records, three float4 each (flat_scene.hpp)
 };
 
 // The small per-model / per-surface tables are read with a wave-uniform index. They are passed to the kernels as
@@ -107,21 +107,37 @@ DEV float tri_test(V3 a, V3 b, V3 c, V3 o, V3 d, float& alpha, float& beta, floa
 	return dist;
 }
 
-// The same solve from a TriIsect record: e1 = a-b, e2 = a-c and c3 come precomputed (identical float operations).
-DEV float tri_test_pre(float4 A, float4 E1, float4 E2, V3 o, V3 d, float& beta, float& gamma) {
-	const V3 v = mk(A.x - o.x, A.y - o.y, A.z - o.z);
-	const float c1 = E2.y * d.z - d.y * E2.z;
-	const float c2 = E1.y * d.z - d.y * E1.z;
-	const float c3 = A.w;
-	const float c4 = v.y * d.z - d.y * v.z;
-	const float c5 = E1.y * v.z - v.y * E1.z;
-	const float c6 = E2.y * v.z - v.y * E2.z;
-	const float inv_det = 1.0f / (E1.x * c1 - E2.x * c2 + d.x * c3);
-	beta = inv_det * (v.x * c1 - E2.x * c4 - d.x * c6);
-	if (beta < 0 - kEps || beta > 1 + kEps) return -1.0f;
-	gamma = inv_det * (E1.x * c4 - v.x * c2 + d.x * c5);
-	if (gamma < 0 - kEps || gamma + beta > 1 + kEps) return -1.0f;
-	return inv_det * (E1.x * c6 - E2.x * c5 + v.x * c3);
+// The same solve from a TriIsect record (e1 = a-b, e2 = a-c and c3 precomputed with identical float operations), written
+// on 2-wide vectors so that it compiles to packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32, operands swizzled with
+// op_sel): every product and every sum is the reference's IEEE operation on the reference's operands, two at a time.
+// The record pairs the edge components so that the cofactors come out as (c1, -c2), (c4, -c4), (c6, -c5): a term the
+// reference subtracts is then added with its sign already flipped, and x + (-y) == x - y, -(x*y) == (-x)*y exactly.
+// Returns the distance, or -1 when the barycentric tests fail (a NaN from a zero determinant fails `t >= 0` later).
+typedef float f2 __attribute__((ext_vector_type(2)));
+DEV f2 swp(f2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+DEV f2 bc(float a) { return (f2){a, a}; }
+struct PRay { f2 oyz, dyz; float ox, dx; };   // the local ray, arranged for tri_test_pk
+DEV PRay pack_ray(V3 o, V3 d) { return {{o.y, o.z}, {d.y, d.z}, o.x, d.x}; }
+DEV float tri_test_pk(float4 r0, float4 r1, float2 r2, const PRay& r, float& beta, float& gamma) {
+	const f2 Pa = {r0.x, r0.y}, Pb = {r0.z, r0.w};               // (e2.y, e1.z), (e2.z, e1.y)
+	const f2 Ex = {r1.x, r1.y}, Ayz = {r1.z, r1.w};              // (e1.x, e2.x), (a.y, a.z)
+	const float c3 = r2.y;
+	const f2 c1n2 = Pa * swp(r.dyz) - Pb * r.dyz;                // (e2.y*d.z - d.y*e2.z, d.y*e1.z - e1.y*d.z) = (c1, -c2)
+	const f2 vyz = Ayz - r.oyz;
+	const float vx = r2.x - r.ox;
+	const f2 m4 = vyz * swp(r.dyz);                              // (v.y*d.z, d.y*v.z)
+	const f2 c4s = m4 - swp(m4);                                 // (c4, -c4)
+	const f2 c6n5 = Pa * swp(vyz) - Pb * vyz;                    // (e2.y*v.z - v.y*e2.z, v.y*e1.z - e1.y*v.z) = (c6, -c5)
+	const f2 t12 = Ex * c1n2;                                    // (e1.x*c1, -(e2.x*c2))
+	const float inv_det = 1.0f / ((t12.x + t12.y) + r.dx * c3);
+	const f2 X = bc(vx) * c1n2 - swp(Ex) * c4s;                  // (v.x*c1 - e2.x*c4, e1.x*c4 - v.x*c2)
+	const f2 N = X - bc(r.dx) * c6n5;                            // (.. - d.x*c6, .. + d.x*c5): numerators of beta, gamma
+	const f2 bg = bc(inv_det) * N;
+	const f2 Z = Ex * c6n5;                                      // (e1.x*c6, -(e2.x*c5))
+	const float t = inv_det * ((Z.x + Z.y) + vx * c3);
+	beta = bg.x; gamma = bg.y;
+	const bool out = (bg.x < 0 - kEps) | (bg.x > 1 + kEps) | (bg.y < 0 - kEps) | (bg.y + bg.x > 1 + kEps);
+	return out ? -1.0f : t;
 }
 
 struct MeshHit { float t; float b1, b2; uint32_t tri; };
@@ -169,6 +185,7 @@ DEV bool aabb_test_inv(const float* mn, const float* mx, V3 o, V3 inv, float& nr
 DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, MeshHit& out, const Spill& spill) {
 	float nr, fr;
 	if (!aabb_test_inv(sf.bmin, sf.bmax, o, inv, nr, fr)) return false;
+	const PRay pr = pack_ray(o, d);
 	int sp = 0;
 	uint32_t n0 = 0, n1 = 0, n2 = 0;  // register stack: entry 0 is the top
 	float m0 = 0, m1 = 0, m2 = 0;
@@ -221,9 +238,10 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, 
 		uint32_t best_tri = 0;
 		for (uint32_t i = 0; i < count; i++) {
 			const uint32_t ti = g.refs[first_ref + i];
-			const float4 A = g.tris[3 * ti], E1 = g.tris[3 * ti + 1], E2 = g.tris[3 * ti + 2];
+			const float4 r0 = g.tris[3 * ti], r1 = g.tris[3 * ti + 1];
+			const float2 r2 = *reinterpret_cast<const float2*>(&g.tris[3 * ti + 2]);
 			float be, ga;
-			const float t = tri_test_pre(A, E1, E2, o, d, be, ga);
+			const float t = tri_test_pk(r0, r1, r2, pr, be, ga);
 			if (t >= 0 && t <= max_dist && (t < best_t || !(best_t >= 0))) { best_t = t; bb1 = be; bb2 = ga; best_tri = ti; }
 		}
 		if (!(best_t >= 0)) continue;

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <limits>
@@ -187,7 +188,7 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 			s.tris.push_back({a[0], a[1], a[2], (uint32_t)(v0 + ix[0]), b[0], b[1], b[2], (uint32_t)(v0 + ix[1]),
 			                  c[0], c[1], c[2], (uint32_t)(v0 + ix[2])});
 			const float e1[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]}, e2[3] = {a[0] - c[0], a[1] - c[1], a[2] - c[2]};
-			s.tri_isect.push_back({a[0], a[1], a[2], e1[1] * e2[2] - e2[1] * e1[2], e1[0], e1[1], e1[2], 0.f, e2[0], e2[1], e2[2], 0.f});
+			s.tri_isect.push_back({e2[1], e1[2], e2[2], e1[1], e1[0], e2[0], a[1], a[2], a[0], e1[1] * e2[2] - e2[1] * e1[2], 0.f, 0.f});
 		}
 		MeshBuilder mbuild{pa, pb, pc, {}, 0};
 		std::vector<uint32_t> all(nt);
@@ -195,24 +196,41 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 		mbuild.build(mb, std::move(all), 25, 1);  // mesh.hpp:34: max_depth = 25
 		s.kd_max_depth = std::max(s.kd_max_depth, mbuild.max_depth_seen);
 
-		// breadth-first emission: children of a branch are adjacent; top levels come first
+		// Emission order. Children of a branch are always adjacent (the node stores the index of the first one).
+		// Chunked order: a node's children, grandchildren and great-grandchildren (<= 14 nodes = 112 bytes) are
+		// written together, then each great-grandchild's own chunk follows depth-first — three tree levels per
+		// 128-byte cache line instead of one, and neighbouring subtrees (and their leaf lists) stay neighbours in
+		// memory. PTX_KD_LAYOUT=bfs selects plain breadth-first order (measurement only).
 		const uint32_t node0 = (uint32_t)s.kd_nodes.size(), ref0 = (uint32_t)s.kd_refs.size();
-		std::deque<std::pair<int32_t, uint32_t>> q;  // (build node, flat index)
+		static const bool bfs_layout = [] { const char* e = getenv("PTX_KD_LAYOUT"); return e && !strcmp(e, "bfs"); }();
+		const int levels_per_chunk = bfs_layout ? (1 << 30) : 3;
 		s.kd_nodes.push_back({0, 0});
-		q.push_back({0, node0});
-		while (!q.empty()) {
-			auto [bi, fi] = q.front();
-			q.pop_front();
-			const BuildNode& bn = mbuild.nodes[bi];
-			if (bn.leaf) {
-				s.kd_nodes[fi] = kd_make_leaf((uint32_t)s.kd_refs.size(), (uint32_t)bn.ids.size());
-				for (uint32_t t : bn.ids) s.kd_refs.push_back((uint32_t)t0 + t);
-			} else {
-				bool hl = bn.left >= 0, hr = bn.right >= 0;
-				uint32_t first = (uint32_t)s.kd_nodes.size();
-				s.kd_nodes[fi] = kd_make_branch(bn.split, bn.axis, hl, hr, first);
-				if (hl) { s.kd_nodes.push_back({0, 0}); q.push_back({bn.left, first}); }
-				if (hr) { s.kd_nodes.push_back({0, 0}); q.push_back({bn.right, first + (hl ? 1u : 0u)}); }
+		std::vector<std::pair<int32_t, uint32_t>> pending{{0, node0}};   // chunk roots (build node, flat index), depth-first
+		std::vector<std::pair<int32_t, uint32_t>> frontier, next;
+		while (!pending.empty()) {
+			frontier.assign(1, pending.back());
+			pending.pop_back();
+			for (int level = 0; !frontier.empty(); level++) {
+				if (level == levels_per_chunk) {
+					// later chunks are taken from the back: push in reverse so that the leftmost subtree comes next
+					for (size_t k = frontier.size(); k-- > 0;) pending.push_back(frontier[k]);
+					break;
+				}
+				next.clear();
+				for (auto [bi, fi] : frontier) {
+					const BuildNode& bn = mbuild.nodes[bi];
+					if (bn.leaf) {
+						s.kd_nodes[fi] = kd_make_leaf((uint32_t)s.kd_refs.size(), (uint32_t)bn.ids.size());
+						for (uint32_t t : bn.ids) s.kd_refs.push_back((uint32_t)t0 + t);
+					} else {
+						bool hl = bn.left >= 0, hr = bn.right >= 0;
+						uint32_t first = (uint32_t)s.kd_nodes.size();
+						s.kd_nodes[fi] = kd_make_branch(bn.split, bn.axis, hl, hr, first);
+						if (hl) { s.kd_nodes.push_back({0, 0}); next.push_back({bn.left, first}); }
+						if (hr) { s.kd_nodes.push_back({0, 0}); next.push_back({bn.right, first + (hl ? 1u : 0u)}); }
+					}
+				}
+				frontier.swap(next);
 			}
 		}
 		sr.kd_root = node0;

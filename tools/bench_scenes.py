@@ -8,6 +8,8 @@ import numpy as np
 import torch
 
 ap = argparse.ArgumentParser(); ap.add_argument("--spp", type=int, default=32); ap.add_argument("--level7", action="store_true")
+ap.add_argument("--only", default="", help="comma list of: cornell, jack, mesh6, mesh7")
+ap.add_argument("--integrator", type=int, default=0)
 args = ap.parse_args()
 ptx = importlib.import_module("distributed-path-tracer_amd")
 proc = importlib.import_module("distributed-path-tracer_amd.procedural")
@@ -16,11 +18,15 @@ W, H, B = 1920, 1080, 8
 accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
 
 
+only = set(filter(None, args.only.split(",")))
+want = lambda k: not only or k in only
+
+
 def run(name, scene, spp):
-    scene.render(W, H, 2, B, accum=accum, want_stats=True)          # warm-up
+    scene.render(W, H, 2, B, accum=accum, want_stats=True, integrator=args.integrator)          # warm-up
     accum.zero_(); torch.cuda.synchronize()
     t = time.perf_counter()
-    _, st = scene.render(W, H, spp, B, accum=accum, want_stats=True)
+    _, st = scene.render(W, H, spp, B, accum=accum, want_stats=True, integrator=args.integrator)
     dt = time.perf_counter() - t
     info = scene.info()
     print(json.dumps({"scene": name, "triangles": info["n_triangles"], "kd_nodes": info["n_kd_nodes"], "lds_resident": info["lds_resident"],
@@ -29,15 +35,16 @@ def run(name, scene, spp):
 
 
 cornell = ptx.Scene.load_gltf(ctx, os.path.join(ROOT, "scenes/cornell-box/cornell.gltf"))
-run("cornell (config 2)", cornell, args.spp)
-run("jack-of-blades (58.7k tris, textures, sun)", ptx.Scene.load_gltf(ctx, os.path.join(ROOT, "scenes/jack-of-blades/jack-of-blades.gltf")), args.spp)
+if want("cornell"): run("cornell (config 2)", cornell, args.spp)
+if want("jack"): run("jack-of-blades (58.7k tris, textures, sun)", ptx.Scene.load_gltf(ctx, os.path.join(ROOT, "scenes/jack-of-blades/jack-of-blades.gltf")), args.spp)
 c = {k: cornell.array(getattr(ptx, "ARR_" + k.upper())) for k in ("model_xform", "model_surf", "surf_range", "vertices", "triangles", "materials", "camera")}
-t0 = time.time()
-d = proc.cornell_with_mesh(c, level=6)
-s6 = ptx.Scene.from_arrays(ctx, d["model_xform"], d["model_surf"], d["surf_range"], d["vertices"], d["triangles"], d["materials"], d["camera"])
-print("level-6 scene build: %.1f s" % (time.time() - t0), flush=True)
-run("cornell + 81 920-triangle mesh (config 3 class)", s6, args.spp)
-if args.level7:
+if want("mesh6"):
+    t0 = time.time()
+    d = proc.cornell_with_mesh(c, level=6)
+    s6 = ptx.Scene.from_arrays(ctx, d["model_xform"], d["model_surf"], d["surf_range"], d["vertices"], d["triangles"], d["materials"], d["camera"])
+    print("level-6 scene build: %.1f s" % (time.time() - t0), flush=True)
+    run("cornell + 81 920-triangle mesh (config 3 class)", s6, args.spp)
+if args.level7 or "mesh7" in only:
     t0 = time.time()
     d = proc.cornell_with_mesh(c, level=7)
     s7 = ptx.Scene.from_arrays(ctx, d["model_xform"], d["model_surf"], d["surf_range"], d["vertices"], d["triangles"], d["materials"], d["camera"])

@@ -1,11 +1,12 @@
 #!/bin/bash
 # Collect PMC counters for the integrator kernel in separate rocprofv3 passes (<= 8 SQ counters each).
-# Usage (on the GPU box, from the repo root): tools/pmc_passes.sh <outdir> [spp]
+# Usage (on the GPU box, from the repo root): tools/pmc_passes.sh <outdir> [spp] [script + args instead of bench.py, e.g. "tools/bench_scenes.py --only mesh6 --spp 8"]
 set -u
 R=$PWD; OUT=$R/${1:-gpurun_out/pmc}; SPP=${2:-16}
+CMD=${3:-"bench.py --steps 1 --warmup 0 --spp $SPP --no-cpu-baseline"}
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 run() { name=$1; shift
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 1 --warmup 0 --spp $SPP --no-cpu-baseline > $OUT/$name.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/$CMD > $OUT/$name.log 2>&1
   echo "$name rc=$?"; }
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES
 run sq2 SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM
