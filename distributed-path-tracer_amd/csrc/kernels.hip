@@ -25,6 +25,20 @@ namespace ptx {
 
 #define DEV __device__ __forceinline__
 
+// PTX_PROF builds (tools/build_variant.sh prof -DPTX_PROF): count wave-level trips and active lanes per code region, to
+// weigh the static instruction counts of the ISA. Not compiled into the product.
+#ifdef PTX_PROF
+struct Prof { uint32_t t[kProfRegions], l[kProfRegions]; };
+#define PROF_ARG , Prof& prof
+#define PROF_PASS , prof
+// every executing lane counts itself; the lowest executing lane also counts the trip (summed over lanes at the end)
+#define PROF(k) do { const uint64_t m_ = __ballot(true); prof.l[k] += 1u; prof.t[k] += ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m_) - 1)) ? 1u : 0u; } while (0)
+#else
+#define PROF_ARG
+#define PROF_PASS
+#define PROF(k) do { } while (0)
+#endif
+
 constexpr float kEps = 0.0001f;                        // math::epsilon (math/math.hpp:16)
 constexpr double kPi = 3.14159265358979323846;         // math::pi is double (math/math.hpp:18)
 constexpr double kInvSqrt3 = 1.0 / 1.7320508075688772; // 1 / math::sqrt3 (util/rand_cone_vec.cpp:23)
@@ -182,7 +196,9 @@ DEV bool aabb_test_inv(const float* mn, const float* mx, V3 o, V3 inv, float& nr
 // Stack entries are (node, min_dist) only: the max_dist the reference stores with an entry is always the
 // min_dist of the entry beneath it (each push hands its old max_dist to the pushed subtree and continues
 // with max_dist = split_dist = the pushed min_dist), and the AABB exit distance for the bottom one.
-DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, MeshHit& out, const Spill& spill) {
+template <int PB>
+DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, MeshHit& out, const Spill& spill PROF_ARG) {
+	PROF(PB);
 	float nr, fr;
 	if (!aabb_test_inv(sf.bmin, sf.bmax, o, inv, nr, fr)) return false;
 	const PRay pr = pack_ray(o, d);
@@ -193,6 +209,7 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, 
 	float min_dist = nr, max_dist = fr;
 	bool have = true;
 	for (;;) {
+		PROF(PB + 1);
 		if (!have) {
 			if (sp == 0) return false;
 			sp--;
@@ -205,6 +222,7 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, 
 		bool valid = true;
 		uint2 nd = g.nodes[node];
 		while ((nd.y & 3u) != KD_LEAF) {
+			PROF(PB + 2);
 			uint32_t axis = nd.y & 3u;
 			float split = __uint_as_float(nd.x);
 			float oa = sel3(o, axis), da = sel3(d, axis);
@@ -237,6 +255,7 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, 
 		float best_t = -1.0f, bb1 = 0, bb2 = 0;
 		uint32_t best_tri = 0;
 		for (uint32_t i = 0; i < count; i++) {
+			PROF(PB + 3);
 			const uint32_t ti = g.refs[first_ref + i];
 			const float4 r0 = g.tris[3 * ti], r1 = g.tris[3 * ti + 1];
 			const float2 r2 = *reinterpret_cast<const float2*>(&g.tris[3 * ti + 2]);
@@ -256,6 +275,9 @@ struct SceneHit { float dist; int surface; uint32_t tri; float b1, b2; };
 
 // renderer::intersect (core/renderer.cpp:645-671) over scene::model::intersect (scene/model.cpp:20-72)
 DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& best, const Spill& spill) {
+#ifdef PTX_PROF
+	Prof prof{};   // not reported: only the EXTEND sweeps of k_render_pass are profiled
+#endif
 	best.dist = -1.0f;
 	best.surface = -1;
 	uint32_t cur_space = 0xFFFFFFFFu;
@@ -279,7 +301,7 @@ DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& 
 		int hit_surface = -1;
 		for (int s = 0; s < M.n_surfaces; s++) {
 			MeshHit h;
-			if (!mesh_traverse(g, S.surfaces[M.first_surface + s], lo, ld, inv, h, spill)) continue;
+			if (!mesh_traverse<4>(g, S.surfaces[M.first_surface + s], lo, ld, inv, h, spill PROF_PASS)) continue;
 			if (h.t < nearest.t || !(nearest.t >= 0)) { nearest = h; hit_surface = M.first_surface + s; }
 		}
 		if (!(nearest.t >= 0)) continue;
@@ -309,14 +331,15 @@ constexpr uint32_t kListCap = (kChunk / 64u) * (kInlineMin - 1u) + 16u;   // ent
 constexpr int kMaxDeferModels = 64;        // per-model list lengths live in the lanes of one VGPR
 
 // Closest hit inside ONE model for a lane that is known to enter its box: scene::model::intersect (model.cpp:27-63)
+template <int PB>
 DEV bool model_traverse(const DevScene& S, const Geom& g, const ModelRec& M, V3 lo, V3 ld, V3 inv, float& wd, int& surf, uint32_t& tri,
-                        float& b1, float& b2, const Spill& spill) {
+                        float& b1, float& b2, const Spill& spill PROF_ARG) {
 	MeshHit nearest;
 	nearest.t = -1.0f;
 	int hit_surface = -1;
 	for (int k = 0; k < M.n_surfaces; k++) {
 		MeshHit h;
-		if (!mesh_traverse(g, S.surfaces[M.first_surface + k], lo, ld, inv, h, spill)) continue;
+		if (!mesh_traverse<PB>(g, S.surfaces[M.first_surface + k], lo, ld, inv, h, spill PROF_PASS)) continue;
 		if (h.t < nearest.t || !(nearest.t >= 0)) { nearest = h; hit_surface = M.first_surface + k; }
 	}
 	if (!(nearest.t >= 0)) return false;
@@ -422,9 +445,9 @@ DEV V3 eval_brdf(V3 n, V3 o, V3 i, V3 albedo, float roughness, float metallic, f
 DEV uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
 	for (int i = 0; i < 10; i++) {
-		uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-		uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-		c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+		// one 32x32->64 multiply per word (v_mad_u64_u32) instead of a mul_hi / mul_lo pair: integer multiplies are quarter rate
+		const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;
+		c = make_uint4((uint32_t)(p1 >> 32) ^ c.y ^ k0, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c.w ^ k1, (uint32_t)p0);
 		k0 += 0x9E3779B9u;
 		k1 += 0xBB67AE85u;
 	}
@@ -740,6 +763,9 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 	float4* lists = hbuf + kChunk + kChunk / 4u;                             // [n_models][2][kListCap]: (local origin, ray index), (local dir, -)
 	const Spill spill{B.spill + (size_t)wave_slot * (kSpillStack * 64) + lane};
 	uint32_t rays = 0;
+#ifdef PTX_PROF
+	Prof prof{};
+#endif
 
 	for (;;) {
 		uint32_t chunk = 0;
@@ -748,6 +774,8 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 		const uint64_t first = (uint64_t)chunk * kChunk;
 		if (first >= P.n_paths) break;
 		uint32_t n_in = (uint32_t)((P.n_paths - first) < (uint64_t)kChunk ? (P.n_paths - first) : kChunk);
+		if (P.bounces == 0)   // trace(0, ..) is black with alpha 1 (renderer.cpp:438-439): no vertex ever stores the sample
+			for (uint32_t i = lane; i < n_in; i += 64) B.sample_rad[(uint32_t)first + i] = make_float4(0.f, 0.f, 0.f, 1.0f);
 
 		for (uint32_t depth = 0; depth < P.bounces && n_in > 0; depth++) {
 			float4* qin = qbase + (size_t)(depth & 1u) * (4u * kChunk);
@@ -763,6 +791,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 				const uint32_t i = base + lane;
 				const bool active = i < n_in;
 				V3 o = {0, 0, 0}, d = {0, 0, 1};
+				if (active) PROF(0);
 				if (active) {
 					if (depth == 0) {
 						const uint32_t id = (uint32_t)first + i;  // id within the pass: sample-major, pixel-minor
@@ -787,7 +816,9 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 					for (int m = 0; m < S.n_models; m++) {
 						const ModelRec& M = S.models[m];
 						const uint32_t spc = S.model_space[m];
+						if (active) PROF(1);
 						if (spc != cur_space) {
+							if (active) PROF(2);
 							const SpaceRec& SP = S.spaces[spc];
 							lo = mulmv(SP.inv_basis, o) + mk(SP.inv_origin[0], SP.inv_origin[1], SP.inv_origin[2]);
 							ld = normalize(mulmv(SP.inv_basis, d));
@@ -801,13 +832,15 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 						const uint32_t cnt = (uint32_t)__popcll(em);
 						if (cnt >= kInlineMin) {
 							if (enters) {
+								PROF(3);
 								float wd, b1, b2; int surf; uint32_t tri;
-								if (model_traverse(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill) &&
+								if (model_traverse<4>(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill PROF_PASS) &&
 								    (wd < h.dist || !(h.dist >= 0) || (wd == h.dist && surf < h.surface))) { h.dist = wd; h.surface = surf; h.tri = tri; h.b1 = b1; h.b2 = b2; }
 							}
 						} else {
 							const uint32_t len = __builtin_amdgcn_readlane(list_len, m);
 							if (enters) {
+								PROF(14);
 								const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
 								// the deferred sweep gets the LOCAL ray: no gather of the stream entry, no second transform
 								float4* L0 = lists + (size_t)m * 2u * kListCap;
@@ -831,6 +864,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 					const float4* L0 = lists + (size_t)m * 2u * kListCap;
 					for (uint32_t base = 0; base < len; base += 64) {
 						if (base + lane < len) {
+							PROF(8);
 							const float4 e0 = L0[base + lane], e1 = L0[kListCap + base + lane];
 							const uint32_t i = __float_as_uint(e0.w);
 							const float bd = hdist[i];                       // current best of this ray: issued before the traversal
@@ -838,7 +872,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 							const V3 lo = mk(e0.x, e0.y, e0.z), ld = mk(e1.x, e1.y, e1.z);
 							const V3 inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
 							float wd, b1, b2; int surf; uint32_t tri;
-							if (model_traverse(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill) &&
+							if (model_traverse<10>(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill PROF_PASS) &&
 							    (wd < bd || !(bd >= 0) || (wd == bd && surf < bs))) {
 								hbuf[i] = make_float4(__int_as_float(surf), __uint_as_float(tri), b1, b2);
 								hdist[i] = wd;
@@ -863,6 +897,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 				uint32_t id = 0;
 				bool alive = false;
 				if (active) {
+					PROF(9);
 					float4 q0 = qin[i], q1 = qin[kChunk + i], hq = hbuf[i];
 					o = mk(q0.x, q0.y, q0.z); id = __float_as_uint(q0.w);
 					d = mk(q1.x, q1.y, q1.z);
@@ -900,6 +935,12 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 	// ray counter: one atomic per wave
 	for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
 	if (lane == 0 && rays) atomicAdd(B.ray_counter, (unsigned long long)rays);
+#ifdef PTX_PROF
+	for (int k = 0; k < kProfRegions; k++) {
+		if (prof.t[k]) atomicAdd(B.ray_counter + 6 + 2 * k, (unsigned long long)prof.t[k]);       // counters block + 64 bytes
+		if (prof.l[k]) atomicAdd(B.ray_counter + 6 + 2 * k + 1, (unsigned long long)prof.l[k]);
+	}
+#endif
 }
 
 // Adds the pass's samples of each pixel, in sample order, into the accumulation buffer (sums).

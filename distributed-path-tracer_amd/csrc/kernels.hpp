@@ -57,6 +57,8 @@ struct RenderParams {
 	uint32_t integrator;        // ptx_integrator
 };
 
+constexpr int kProfRegions = 16;   // PTX_PROF builds only: (wave-level trips, active lanes) per code region
+
 struct PassBuffers {
 	float4* queues;                   // [n_wave_slots][kQueueFloat4PerWave]
 	float4* sample_rad;               // [pass_spp][n_pixels]

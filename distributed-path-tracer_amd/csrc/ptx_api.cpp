@@ -375,7 +375,7 @@ int64_t ptx_scene_get_array(const ptx_scene* sc, ptx_array which, void* dst, siz
 int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_render_stats* stats) {
 	if (!sc || !cfg || !accum) return set_err(PTX_ERR_INVALID, "ptx_render: NULL argument");
 	if (!sc->ctx) return set_err(PTX_ERR_NO_DEVICE, "ptx_render: scene was created without a GPU context (no CPU path exists)");
-	if (!cfg->W || !cfg->H || !cfg->bounces) return set_err(PTX_ERR_INVALID, "ptx_render: W, H and bounces must be > 0");
+	if (!cfg->W || !cfg->H) return set_err(PTX_ERR_INVALID, "ptx_render: W and H must be > 0");   // bounces = 0 is legal: a black frame (renderer.cpp:438-439)
 	uint32_t x0 = cfg->x0, y0 = cfg->y0, w = cfg->w, h = cfg->h;
 	if (w == 0 && h == 0) { x0 = 0; y0 = 0; w = cfg->W; h = cfg->H; }
 	if (!w || !h || (uint64_t)x0 + w > cfg->W || (uint64_t)y0 + h > cfg->H) return set_err(PTX_ERR_INVALID, "ptx_render: tile outside the image");
@@ -403,11 +403,11 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 	const size_t n_slots = (size_t)grid * (kBlock / 64);
 	HIP_TRY(c->queues.ensure(n_slots * (size_t)kQueueFloat4PerWave * sizeof(float4)));
 	HIP_TRY(c->sample_rad.ensure((size_t)pass_spp * n_pixels * sizeof(float4)));
-	HIP_TRY(c->counters.ensure(64));
+	HIP_TRY(c->counters.ensure(1024));   // [0] chunk counter, [16] ray counter, [64..] PTX_PROF region counters
 	HIP_TRY(c->spill.ensure(n_slots * (size_t)kSpillWords * sizeof(uint2)));
 	uint32_t* chunk_counter = (uint32_t*)c->counters.p;
 	unsigned long long* ray_counter = (unsigned long long*)((char*)c->counters.p + 16);
-	HIP_TRY(hipMemsetAsync(c->counters.p, 0, 64, c->stream));
+	HIP_TRY(hipMemsetAsync(c->counters.p, 0, 1024, c->stream));
 
 	const bool dev_accum = is_device_ptr(accum);
 	float4* d_accum = (float4*)accum;
@@ -457,6 +457,16 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 			ms += t;
 		}
 		stats->kernel_ms = ms;
+#ifdef PTX_PROF
+		unsigned long long prof[2 * kProfRegions];
+		HIP_TRY(hipMemcpy(prof, (char*)c->counters.p + 64, sizeof prof, hipMemcpyDeviceToHost));
+		static const char* names[kProfRegions] = {"extend_iter", "model_iter", "space_xform", "inline_model", "mesh_call", "mesh_pop", "node_step",
+		                                           "tri_test", "defer_iter", "shade_iter", "defer_mesh_call", "defer_mesh_pop", "defer_node_step", "defer_tri_test",
+		                                           "list_append", "shade_hit"};
+		for (int k = 0; k < kProfRegions; k++)
+			fprintf(stderr, "PROF %-16s trips %12llu lanes %14llu  util %.3f  trips/64rays %.3f\n", names[k], prof[2 * k], prof[2 * k + 1],
+			        prof[2 * k] ? (double)prof[2 * k + 1] / (64.0 * prof[2 * k]) : 0.0, (double)prof[2 * k] / ((double)rays / 64.0));
+#endif
 	}
 	return PTX_OK;
 }

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 ap = argparse.ArgumentParser(); ap.add_argument("--spp", type=int, default=32); ap.add_argument("--level7", action="store_true")
-ap.add_argument("--only", default="", help="comma list of: cornell, jack, mesh6, mesh7")
+ap.add_argument("--only", default="", help="comma list of: cornell, jack, plaza, mesh6, mesh7")
 ap.add_argument("--integrator", type=int, default=0)
 args = ap.parse_args()
 ptx = importlib.import_module("distributed-path-tracer_amd")
@@ -38,6 +38,10 @@ cornell = ptx.Scene.load_gltf(ctx, os.path.join(ROOT, "scenes/cornell-box/cornel
 if want("cornell"): run("cornell (config 2)", cornell, args.spp)
 if want("jack"): run("jack-of-blades (58.7k tris, textures, sun)", ptx.Scene.load_gltf(ctx, os.path.join(ROOT, "scenes/jack-of-blades/jack-of-blades.gltf")), args.spp)
 c = {k: cornell.array(getattr(ptx, "ARR_" + k.upper())) for k in ("model_xform", "model_surf", "surf_range", "vertices", "triangles", "materials", "camera")}
+if want("plaza"):
+    d = proc.plaza_scene(level=5, sun=True, alpha=True)
+    sp = ptx.Scene.from_arrays(ctx, d["model_xform"], d["model_surf"], d["surf_range"], d["vertices"], d["triangles"], d["materials"], d["camera"], d["sun"])
+    run("plaza: sun + shadow catcher + translucent sphere (25.6k tris)", sp, args.spp)
 if want("mesh6"):
     t0 = time.time()
     d = proc.cornell_with_mesh(c, level=6)
