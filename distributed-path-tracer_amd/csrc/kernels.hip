@@ -326,6 +326,35 @@ DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& 
 #ifndef PTX_INLINE_MIN
 #define PTX_INLINE_MIN 32
 #endif
+// renderer::intersect(shadow ray).has_hit() (renderer.cpp:509-511, intersection_worker.cpp:58-61): the reference finds the closest
+// hit and then only asks whether there is one, so the sweep may stop at the first model that reports a hit.
+DEV bool scene_occluded(const DevScene& S, const Geom& g, V3 o, V3 d, const Spill& spill) {
+#ifdef PTX_PROF
+	Prof prof{};
+#endif
+	uint32_t cur_space = 0xFFFFFFFFu;
+	V3 lo = o, ld = d, inv = d;
+	for (int m = 0; m < S.n_models; m++) {
+		const ModelRec& M = S.models[m];
+		const uint32_t spc = S.model_space[m];   // wave-uniform
+		if (spc != cur_space) {
+			const SpaceRec& SP = S.spaces[spc];
+			lo = mulmv(SP.inv_basis, o) + mk(SP.inv_origin[0], SP.inv_origin[1], SP.inv_origin[2]);
+			ld = normalize(mulmv(SP.inv_basis, d));
+			inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+			cur_space = spc;
+		}
+		float nr, fr;
+		if (!aabb_test_inv(M.bmin, M.bmax, lo, inv, nr, fr)) continue;
+		for (int s = 0; s < M.n_surfaces; s++) {
+			MeshHit h;
+			if (!mesh_traverse<4>(g, S.surfaces[M.first_surface + s], lo, ld, inv, h, spill PROF_PASS)) continue;
+			if (length(mulmv(M.basis, ld * h.t)) >= 0) return true;   // model.cpp:62-63: a hit whose world distance is not NaN
+		}
+	}
+	return false;
+}
+
 constexpr uint32_t kInlineMin = PTX_INLINE_MIN;        // lanes of a wave-iteration that make a model worth traversing on the spot
 constexpr uint32_t kListCap = (kChunk / 64u) * (kInlineMin - 1u) + 16u;   // entries a list can receive per chunk (kChunk / 64 iterations)
 constexpr int kMaxDeferModels = 64;        // per-model list lengths live in the lanes of one VGPR
@@ -544,174 +573,120 @@ DEV MatEval material_eval(const DevScene& S, const MaterialRec& m, float u, floa
 }
 
 // ------------------------------------------------------------------------------------ one path vertex
-// renderer::trace (core/renderer.cpp:437-643) in iterative throughput form (DESIGN.md "Estimator"):
+// The shading phase never traverses. What the reference does with a second intersect() call from inside trace() becomes a
+// record handed to the next sweep of the wave's stream:
+//   * opacity / lit-shadow-catcher pass-through (renderer.cpp:466-472, 513-519): the same path, same depth, pass + 1,
+//     continued from behind the surface — an ordinary entry of the outgoing ray stream;
+//   * the sun sample (renderer.cpp:498-564): a SHADOW REQUEST (ray + what to do with the answer), resolved by the
+//     any-hit sweep that follows the shading sweep.
+// Vertex outcomes:
+enum : int {
+	V_DEAD = 0,      // path ends; L is final unless a request of kind REQ_ADD is pending for it
+	V_ALIVE = 1,     // (o, d, T, L, depth, pass) updated: next stream entry
+	V_PENDING = 2,   // shadow catcher: the request's answer decides between pass-through and the end of the path
+};
+enum : uint32_t { REQ_NONE = 0, REQ_ADD = 1, REQ_CATCHER = 2 };
+struct ShadowReq {
+	uint32_t kind;
+	V3 o, d;     // the shadow ray
+	V3 x;        // REQ_ADD: T * direct_out, added to the path's radiance when unoccluded; REQ_CATCHER: origin of the pass-through ray
+};
+
+// PTX_INTEGRATOR_LIB — renderer::trace (core/renderer.cpp:437-643) in iterative throughput form (DESIGN.md "Estimator"):
 //   L += T * (direct + emissive);  T *= clamp(brdf / max(pdf, eps), 0, 1);  next ray.
-// `h` is the closest hit of (o, d) found by the extend phase. Returns true when the path continues with
-// (o, d) updated. SUN / ALPHA select the code that needs a second traversal from inside the shading phase
-// (sun shadow rays; opacity / shadow-catcher pass-through): scenes without them get a kernel without it.
-template <bool SUN, bool ALPHA, bool TEX>
-DEV bool shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, const RenderParams& P, uint32_t pixel, uint32_t sample,
-                      uint32_t depth, SceneHit h, V3& o, V3& d, V3& T, V3& L, uint32_t& rays, const Spill& spill) {
-	uint32_t pass = 0;
-	for (;;) {
-		if (h.surface < 0) {
-			L = L + T * mk(P.env[0], P.env[1], P.env[2]);  // miss: environment_factor (renderer.cpp:443-451)
-			return false;
-		}
-		const ShadeRec& R = shade[h.surface];
-		Surf sf;
-		hit_attributes(S, g, R, h.tri, h.b1, h.b2, sf);
-		const MaterialRec& mt = R.mat;
-		const MatEval me = material_eval<TEX>(S, mt, sf.u, sf.v);   // renderer.cpp:458-462
-		V3 albedo = me.albedo;
-		float roughness = me.roughness, metallic = me.metallic;
-		float4 rnd = draws(P, pixel, sample, depth, pass, BLOCK_SURFACE);  // x opacity, y lobe, z/w BSDF sample
-
-		bool pass_through = false;
-		if constexpr (ALPHA) {
-			float opacity = me.opacity;
-			pass_through = !(opacity == 1.0f || fabsf(opacity - 1.0f) < kEps) && rnd.x > opacity;  // renderer.cpp:466-472
-		}
-		V3 normal = mk(0, 0, 0), outcoming = -d;
-		float spec_prob = 0;
-		if (!pass_through) {
-			normal = shading_normal(sf, me.normal_ts);
-			if (dot(normal, outcoming) <= 0) return false;                  // renderer.cpp:478-479: black, path ends
-			roughness = pmax(roughness, 0.05F);
-			spec_prob = fresnel_schlick(outcoming, reflect3(-outcoming, normal), mt.ior);
-			spec_prob = pmax(spec_prob, metallic);
-		}
-		V3 direct_out = mk(0, 0, 0);
-		if constexpr (SUN) {
-			if (S.sun.present && !pass_through) {                                             // renderer.cpp:498-564
-				float4 sr = draws(P, pixel, sample, depth, pass, BLOCK_SUN);
-				V3 din = mulmv(S.sun.basis, mk(0, 0, 1));
-				din = rand_cone_vec(sr.x, cosf(sr.y * S.sun.angular_radius), din);
-				if (dot(normal, din) > 0) {
-					V3 so = sf.pos + din * kEps, sd = normalize(din);
-					SceneHit sh;
-					rays++;
-					bool shadowed = scene_traverse(S, g, so, sd, sh, spill);
-					bool catcher = ALPHA && mt.shadow_catcher && depth == 0;
-					if (!shadowed) {
-						if (catcher) pass_through = true;                    // lit shadow catcher behaves as fully transparent
-						else {
-							float pdf_unused;
-							V3 brdf = eval_brdf(normal, outcoming, din, albedo, roughness, metallic, spec_prob, pdf_unused);
-							V3 e = mk(S.sun.energy[0], S.sun.energy[1], S.sun.energy[2]);
-							float pdf = lerpf(1.0f, 1.0f, spec_prob);
-							V3 v = brdf * e / pmax(pdf, kEps);
-							direct_out = mk(clampf(v.x, 0, e.x), clampf(v.y, 0, e.y), clampf(v.z, 0, e.z));
-						}
-					} else if (catcher) return false;                        // shadowed catcher: black
-				}
-			}
-		}
-		if constexpr (ALPHA) {
-			if (pass_through) {
-				o = sf.pos + d * kEps;
-				d = normalize(d);
-				pass++;
-				if (pass > 4096) return false;  // safety bound; the reference would recurse without limit
-				rays++;
-				scene_traverse(S, g, o, d, h, spill);
-				continue;
-			}
-		}
-		V3 inc = (rnd.y < spec_prob) ? importance_specular(rnd.z, rnd.w, normal, outcoming, roughness)
-		                              : importance_diffuse(rnd.z, rnd.w, normal);
-		L = L + T * (direct_out + me.emissive10);
-		if (!(dot(normal, inc) > 0)) return false;                           // renderer.cpp:578: no indirect term
-		float pdf;
-		V3 brdf = eval_brdf(normal, outcoming, inc, albedo, roughness, metallic, spec_prob, pdf);
-		float ip = pmax(pdf, kEps);
-		T = T * mk(clampf(brdf.x / ip, 0, 1), clampf(brdf.y / ip, 0, 1), clampf(brdf.z / ip, 0, 1));  // renderer.cpp:617-620
-		o = sf.pos + inc * kEps;
-		d = normalize(inc);
-		return true;
+// PTX_INTEGRATOR_WORKER — one vertex of the HOST worker's stage pipeline: INTERSECT's sun sample
+// (src/processors/worker/intersection_worker.cpp:22-39), SHADING (shading_worker.cpp:27-199); `L` is cloud_ray::color,
+// `T` cloud_ray::scale, `depth` = bounce_count - cloud_ray::bounce.
+// `h` is the closest hit of (o, d) found by the extend sweep. SUN / ALPHA compile the request / pass-through code in.
+template <bool SUN, bool ALPHA, bool TEX, bool WORKER>
+DEV int shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, const RenderParams& P, uint32_t pixel, uint32_t sample,
+                     uint32_t& depth, uint32_t& pass, SceneHit h, V3& o, V3& d, V3& T, V3& L, ShadowReq& rq) {
+	rq.kind = REQ_NONE;
+	if (h.surface < 0) {
+		L = L + T * mk(P.env[0], P.env[1], P.env[2]);  // miss: environment_factor (renderer.cpp:443-451, shading_worker.cpp:28-41)
+		return V_DEAD;
 	}
-}
+	const ShadeRec& R = shade[h.surface];
+	Surf sf;
+	hit_attributes(S, g, R, h.tri, h.b1, h.b2, sf);
+	const MaterialRec& mt = R.mat;
+	const MatEval me = material_eval<TEX>(S, mt, sf.u, sf.v);   // renderer.cpp:458-462
+	float roughness = me.roughness;
+	const float4 rnd = draws(P, pixel, sample, depth, pass, BLOCK_SURFACE);  // x opacity, y lobe, z/w BSDF sample
+	if constexpr (WORKER) L = L + T * me.emissive10;                         // shading_worker.cpp:52 — before the opacity test
 
-// One vertex of the HOST worker's stage pipeline (PTX_INTEGRATOR_WORKER): INTERSECT's sun sample
-// (src/processors/worker/intersection_worker.cpp:22-39), DIRECT_LIGHTING's shadow query (:58-64) and SHADING
-// (shading_worker.cpp:27-199) for one worker. `L` is cloud_ray::color, `T` cloud_ray::scale; `depth` = bounce_count -
-// cloud_ray::bounce. The shadow query is issued only when its result is read (same image, fewer rays).
-template <bool TEX>
-DEV bool shade_vertex_worker(const DevScene& S, const Geom& g, const ShadeRec* shade, const RenderParams& P, uint32_t pixel, uint32_t sample,
-                             uint32_t depth, SceneHit h, V3& o, V3& d, V3& T, V3& L, uint32_t& rays, const Spill& spill) {
-	uint32_t pass = 0;
-	for (;;) {
-		if (h.surface < 0) {
-			L = L + T * mk(P.env[0], P.env[1], P.env[2]);                       // shading_worker.cpp:28-41
-			return false;
-		}
-		const ShadeRec& R = shade[h.surface];
-		Surf sf;
-		hit_attributes(S, g, R, h.tri, h.b1, h.b2, sf);
-		const MaterialRec& mt = R.mat;
-		const MatEval me = material_eval<TEX>(S, mt, sf.u, sf.v);
-		float roughness = me.roughness;
-		const float4 rnd = draws(P, pixel, sample, depth, pass, BLOCK_SURFACE);   // x opacity, y lobe, z/w BSDF sample
-		const float4 sr = draws(P, pixel, sample, depth, pass, BLOCK_SUN);        // x azimuth, y cone angle, z Russian roulette
-		L = L + T * me.emissive10;                                              // :52 — before the opacity test
-		bool pass_through = !(me.opacity == 1.0f || fabsf(me.opacity - 1.0f) < kEps) && rnd.x > me.opacity;   // :54
-		V3 normal = mk(0, 0, 0), outcoming = -d, din = mk(0, 0, 0);
-		bool lit = false;
-		if (!pass_through) {
-			normal = shading_normal(sf, me.normal_ts);
-			if (dot(normal, outcoming) <= 0) return false;                      // :68-72
-			if (S.sun.present) {
-				V3 c = mulmv(S.sun.basis, mk(0, 0, 1));
-				c = rand_cone_vec(sr.x, cosf(sr.y * S.sun.angular_radius), c);
-				din = normalize(c);                                             // ray::get_dir()
-				if (dot(normal, c) > 0 && dot(normal, din) > 0) {               // intersection_worker.cpp:33, shading_worker.cpp:80/115
-					SceneHit sh;
-					rays++;
-					lit = !scene_traverse(S, g, sf.pos + c * kEps, din, sh, spill);
-				}
-			}
-			if (mt.shadow_catcher && depth == 0) {                              // :74-105
-				if (!lit) { L = mk(0, 0, 0); return false; }
-				pass_through = true;
-			}
-		}
-		if (pass_through) {
+	if constexpr (ALPHA) {
+		const bool transparent = !(me.opacity == 1.0f || fabsf(me.opacity - 1.0f) < kEps) && rnd.x > me.opacity;   // renderer.cpp:466-472
+		if (transparent) {
 			o = sf.pos + d * kEps;
 			d = normalize(d);
 			pass++;
-			if (pass > 4096) return false;  // safety bound; the reference re-queues without limit
-			rays++;
-			scene_traverse(S, g, o, d, h, spill);
-			continue;
+			return pass > 4096 ? V_DEAD : V_ALIVE;   // safety bound; the reference would recurse / re-queue without limit
 		}
-		roughness = pmax(roughness, 0.05F);
-		float spec_prob = fresnel_schlick(outcoming, reflect3(-outcoming, normal), mt.ior);
-		spec_prob = pmax(spec_prob, me.metallic);
-		if (lit) {                                                              // :119-143
+	}
+	const V3 normal = shading_normal(sf, me.normal_ts), outcoming = -d;
+	if (dot(normal, outcoming) <= 0) return V_DEAD;                          // renderer.cpp:478-479: black, path ends
+	roughness = pmax(roughness, 0.05F);
+	float spec_prob = fresnel_schlick(outcoming, reflect3(-outcoming, normal), mt.ior);
+	spec_prob = pmax(spec_prob, me.metallic);
+
+	V3 direct_out = mk(0, 0, 0);   // LIB without a request: stays 0
+	if constexpr (SUN) {
+		const bool catcher = ALPHA && mt.shadow_catcher && depth == 0;
+		bool sampled = false;
+		V3 din = mk(0, 0, 0);
+		if (S.sun.present) {                                                  // renderer.cpp:498-509 / intersection_worker.cpp:22-39
+			const float4 sr = draws(P, pixel, sample, depth, pass, BLOCK_SUN);
+			V3 c = mulmv(S.sun.basis, mk(0, 0, 1));
+			c = rand_cone_vec(sr.x, cosf(sr.y * S.sun.angular_radius), c);
+			const V3 cn = normalize(c);                                       // ray::get_dir()
+			din = WORKER ? cn : c;                                            // the worker shades with the ray's direction, trace() with the sample
+			sampled = dot(normal, c) > 0 && (!WORKER || dot(normal, cn) > 0);
+			if (sampled) { rq.o = sf.pos + c * kEps; rq.d = cn; }
+		}
+		if (WORKER && catcher && !sampled) { L = mk(0, 0, 0); return V_DEAD; }   // shading_worker.cpp:74-94: in_shadow stays true
+		if (sampled) {
+			if (catcher) {                                                    // lit: transparent; shadowed: black (renderer.cpp:513-519,560-561)
+				rq.kind = REQ_CATCHER;
+				rq.x = sf.pos + d * kEps;
+				return V_PENDING;
+			}
 			float pdf_unused;
-			V3 brdf = eval_brdf(normal, outcoming, din, me.albedo, roughness, me.metallic, spec_prob, pdf_unused);
-			V3 e = mk(S.sun.energy[0], S.sun.energy[1], S.sun.energy[2]);
-			float pdf = lerpf(1.0f, 1.0f, spec_prob);
-			V3 v = brdf * e / pmax(pdf, kEps);
-			L = L + T * mk(clampf(v.x, 0, e.x), clampf(v.y, 0, e.y), clampf(v.z, 0, e.z));
+			const V3 brdf = eval_brdf(normal, outcoming, din, me.albedo, roughness, me.metallic, spec_prob, pdf_unused);
+			const V3 e = mk(S.sun.energy[0], S.sun.energy[1], S.sun.energy[2]);
+			const float pdf = lerpf(1.0f, 1.0f, spec_prob);
+			const V3 v = brdf * e / pmax(pdf, kEps);
+			direct_out = mk(clampf(v.x, 0, e.x), clampf(v.y, 0, e.y), clampf(v.z, 0, e.z));
+			rq.kind = REQ_ADD;
+			rq.x = T * direct_out;
 		}
-		V3 inc = (rnd.y < spec_prob) ? importance_specular(rnd.z, rnd.w, normal, outcoming, roughness)
-		                              : importance_diffuse(rnd.z, rnd.w, normal);
-		if (!(dot(normal, inc) > 0)) return false;                              // :154, :196-199
-		float pdf;
-		V3 brdf = eval_brdf(normal, outcoming, inc, me.albedo, roughness, me.metallic, spec_prob, pdf);
-		float ip = pmax(pdf, kEps);
-		T = T * mk(brdf.x / ip, brdf.y / ip, brdf.z / ip);                      // :173
-		T = mk(clampf(T.x, 0, 10.0f), clampf(T.y, 0, 10.0f), clampf(T.z, 0, 10.0f));   // :175
-		o = sf.pos + inc * kEps;
-		d = normalize(inc);
-		if ((int)(P.bounces - depth) < (int)P.bounces - 2) {                    // :182-190
+	}
+	const V3 inc = (rnd.y < spec_prob) ? importance_specular(rnd.z, rnd.w, normal, outcoming, roughness)
+	                                    : importance_diffuse(rnd.z, rnd.w, normal);
+	if constexpr (!WORKER) L = L + T * me.emissive10;
+	if (!(dot(normal, inc) > 0)) return V_DEAD;                              // renderer.cpp:578 / shading_worker.cpp:154,196-199
+	float pdf;
+	const V3 brdf = eval_brdf(normal, outcoming, inc, me.albedo, roughness, me.metallic, spec_prob, pdf);
+	const float ip = pmax(pdf, kEps);
+	if constexpr (!WORKER) {
+		T = T * mk(clampf(brdf.x / ip, 0, 1), clampf(brdf.y / ip, 0, 1), clampf(brdf.z / ip, 0, 1));  // renderer.cpp:617-620
+	} else {
+		T = T * mk(brdf.x / ip, brdf.y / ip, brdf.z / ip);                                           // shading_worker.cpp:173
+		T = mk(clampf(T.x, 0, 10.0f), clampf(T.y, 0, 10.0f), clampf(T.z, 0, 10.0f));                 // :175
+	}
+	o = sf.pos + inc * kEps;
+	d = normalize(inc);
+	if constexpr (WORKER) {
+		if ((int)(P.bounces - depth) < (int)P.bounces - 2) {                 // :182-190, Russian roulette
+			const float4 sr = draws(P, pixel, sample, depth, pass, BLOCK_SUN);   // lane z
 			const float p = pmax(T.x, pmax(T.y, T.z));
-			if (sr.z > p) return false;
+			if (sr.z > p) return V_DEAD;
 			T = mk(T.x / p, T.y / p, T.z / p);
 		}
-		return true;
 	}
+	depth++;
+	pass = 0;
+	return depth == P.bounces ? V_DEAD : V_ALIVE;                            // trace(0, ..) is black: renderer.cpp:438-439; bounce > 0: shading_worker.cpp:193
 }
 
 // ------------------------------------------------------------------------------------ LDS staging
@@ -760,7 +735,8 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 	float4* qbase = B.queues + (size_t)wave_slot * (kQueueFloat4PerWave);
 	float4* hbuf = qbase + 2u * 4u * kChunk;
 	float* hdist = reinterpret_cast<float*>(hbuf + kChunk);                 // [kChunk] world distance of the current best hit (deferral)
-	float4* lists = hbuf + kChunk + kChunk / 4u;                             // [n_models][2][kListCap]: (local origin, ray index), (local dir, -)
+	float4* sreq = hbuf + kChunk + kChunk / 4u;                              // [3][kChunk] shadow requests: (origin, target) (dir, kind) (x, path id)
+	float4* lists = sreq + 3u * kChunk;                                      // [n_models][2][kListCap]: (local origin, ray index), (local dir, -)
 	const Spill spill{B.spill + (size_t)wave_slot * (kSpillStack * 64) + lane};
 	uint32_t rays = 0;
 #ifdef PTX_PROF
@@ -777,15 +753,16 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 		if (P.bounces == 0)   // trace(0, ..) is black with alpha 1 (renderer.cpp:438-439): no vertex ever stores the sample
 			for (uint32_t i = lane; i < n_in; i += 64) B.sample_rad[(uint32_t)first + i] = make_float4(0.f, 0.f, 0.f, 1.0f);
 
-		for (uint32_t depth = 0; depth < P.bounces && n_in > 0; depth++) {
-			float4* qin = qbase + (size_t)(depth & 1u) * (4u * kChunk);
-			float4* qout = qbase + (size_t)((depth + 1u) & 1u) * (4u * kChunk);
-			const bool last = depth + 1 == P.bounces;
+		// One step = every live path of the chunk advances by one stream entry: a scatter (depth + 1) or, with ALPHA, a
+		// pass-through (same depth, pass + 1). Without pass-through all paths of a step have depth == step.
+		for (uint32_t step = 0; P.bounces > 0 && n_in > 0; step++) {
+			float4* qin = qbase + (size_t)(step & 1u) * (4u * kChunk);
+			float4* qout = qbase + (size_t)((step + 1u) & 1u) * (4u * kChunk);
 
 			// ---------------- EXTEND
 			// lists live in the unused part of the wave's stream area: hdist (kChunk words) + n_models lists
 			const bool defer = S.n_models <= kMaxDeferModels && S.n_models > 1 &&
-			                   (uint32_t)S.n_models * 2u * kListCap + kChunk / 4u <= kQueueFloat4PerWave - 9u * kChunk;
+			                   (uint32_t)S.n_models * 2u * kListCap + kChunk / 4u <= kQueueFloat4PerWave - 12u * kChunk;
 			uint32_t list_len = 0;   // lane m: entries in model m's deferred list
 			for (uint32_t base = 0; base < n_in; base += 64) {
 				const uint32_t i = base + lane;
@@ -793,7 +770,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 				V3 o = {0, 0, 0}, d = {0, 0, 1};
 				if (active) PROF(0);
 				if (active) {
-					if (depth == 0) {
+					if (step == 0) {
 						const uint32_t id = (uint32_t)first + i;  // id within the pass: sample-major, pixel-minor
 						const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
 						const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
@@ -888,48 +865,121 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-			// ---------------- SHADE + wave-level stream compaction
-			uint32_t n_out = 0;
+			// ---------------- SHADE + wave-level stream compaction (rays and shadow requests)
+			uint32_t n_out = 0, n_sh = 0;
 			for (uint32_t base = 0; base < n_in; base += 64) {
 				const uint32_t i = base + lane;
 				const bool active = i < n_in;
 				V3 o = {0, 0, 0}, d = {0, 0, 1}, T = {1, 1, 1}, L = {0, 0, 0};
-				uint32_t id = 0;
-				bool alive = false;
+				uint32_t id = 0, depth = ALPHA ? 0u : step, pass = 0;
+				int state = V_DEAD;
+				ShadowReq rq;
+				rq.kind = REQ_NONE;
 				if (active) {
 					PROF(9);
 					float4 q0 = qin[i], q1 = qin[kChunk + i], hq = hbuf[i];
 					o = mk(q0.x, q0.y, q0.z); id = __float_as_uint(q0.w);
 					d = mk(q1.x, q1.y, q1.z);
-					if (depth != 0) {
+					if (step != 0) {
 						float4 q2 = qin[2 * kChunk + i], q3 = qin[3 * kChunk + i];
 						T = mk(q1.w, q2.x, q2.y);
 						L = mk(q2.z, q2.w, q3.x);
+						if constexpr (ALPHA) { const uint32_t dp = __float_as_uint(q3.y); depth = dp >> 16; pass = dp & 0xFFFFu; }
 					}
 					SceneHit h;
 					h.dist = 0; h.surface = __float_as_int(hq.x); h.tri = __float_as_uint(hq.y); h.b1 = hq.z; h.b2 = hq.w;
 					const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
 					const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
-					if constexpr (WORKER)
-						alive = shade_vertex_worker<TEX>(S, g, st.shade, P, py * P.W + px, P.sample0 + s_local, depth, h, o, d, T, L, rays, spill);
-					else
-						alive = shade_vertex<SUN, ALPHA, TEX>(S, g, st.shade, P, py * P.W + px, P.sample0 + s_local, depth, h, o, d, T, L, rays, spill);
-					if (last) alive = false;  // trace(0, ..) returns black: renderer.cpp:438-439
-					if (!alive) B.sample_rad[id] = make_float4(L.x, L.y, L.z, 1.0f);
+					state = shade_vertex<SUN, ALPHA, TEX, WORKER>(S, g, st.shade, P, py * P.W + px, P.sample0 + s_local, depth, pass, h, o, d, T, L, rq);
+					if (state == V_DEAD) B.sample_rad[id] = make_float4(L.x, L.y, L.z, 1.0f);
 				}
+				const bool alive = state == V_ALIVE;
 				const uint64_t mask = __ballot(alive);
+				const uint32_t pos = n_out + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 				if (alive) {
-					const uint32_t pos = n_out + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 					qout[pos] = make_float4(o.x, o.y, o.z, __uint_as_float(id));
 					qout[kChunk + pos] = make_float4(d.x, d.y, d.z, T.x);
 					qout[2 * kChunk + pos] = make_float4(T.y, T.z, L.x, L.y);
-					qout[3 * kChunk + pos] = make_float4(L.z, 0.f, 0.f, 0.f);
+					qout[3 * kChunk + pos] = make_float4(L.z, __uint_as_float((depth << 16) | pass), 0.f, 0.f);
 				}
 				n_out += (uint32_t)__popcll(mask);
+				if constexpr (SUN) {
+					const bool want = rq.kind != REQ_NONE;
+					const uint64_t sm = __ballot(want);
+					if (want) {
+						const uint32_t sp = n_sh + __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+						// where the answer goes: the path's new stream entry, its final sample (0xFFFFFFFF), or — shadow catcher — its current entry
+						const uint32_t target = rq.kind == REQ_CATCHER ? i : (alive ? pos : 0xFFFFFFFFu);
+						sreq[sp] = make_float4(rq.o.x, rq.o.y, rq.o.z, __uint_as_float(target));
+						sreq[kChunk + sp] = make_float4(rq.d.x, rq.d.y, rq.d.z, __uint_as_float(rq.kind));
+						sreq[2 * kChunk + sp] = make_float4(rq.x.x, rq.x.y, rq.x.z, __uint_as_float(id));
+						if (rq.kind == REQ_CATCHER) {   // the pass-through entry is built from the current one: make its path state complete
+							qin[2 * kChunk + i] = make_float4(T.y, T.z, L.x, L.y);
+							qin[3 * kChunk + i] = make_float4(L.z, __uint_as_float((depth << 16) | pass), 0.f, 0.f);
+						}
+					}
+					n_sh += (uint32_t)__popcll(sm);
+				}
 			}
-			n_in = n_out;
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+			// ---------------- SHADOW: any-hit sweep over the requests of this step
+			if constexpr (SUN) {
+				for (uint32_t base = 0; base < n_sh; base += 64) {
+					const uint32_t j = base + lane;
+					bool through = false;
+					uint32_t target = 0, id = 0;
+					V3 x = {0, 0, 0};
+					if (j < n_sh) {
+						const float4 r0 = sreq[j], r1 = sreq[kChunk + j], r2 = sreq[2 * kChunk + j];
+						target = __float_as_uint(r0.w); id = __float_as_uint(r2.w);
+						x = mk(r2.x, r2.y, r2.z);
+						const bool occluded = scene_occluded(S, g, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), spill);
+						if (__float_as_uint(r1.w) == REQ_ADD) {
+							if (!occluded) {
+								if (target == 0xFFFFFFFFu) {
+									float4 v = B.sample_rad[id];
+									B.sample_rad[id] = make_float4(v.x + x.x, v.y + x.y, v.z + x.z, v.w);
+								} else {
+									float4 q2 = qout[2 * kChunk + target];
+									float* lz = reinterpret_cast<float*>(qout + 3 * kChunk + target);
+									qout[2 * kChunk + target] = make_float4(q2.x, q2.y, q2.z + x.x, q2.w + x.y);
+									*lz = *lz + x.z;
+								}
+							}
+						} else if (occluded) {   // shadowed catcher: the path ends — trace() returns what it has (black), the worker zeroes the colour
+							const float4 q2 = qin[2 * kChunk + target], q3 = qin[3 * kChunk + target];
+							B.sample_rad[id] = WORKER ? make_float4(0.f, 0.f, 0.f, 1.0f) : make_float4(q2.z, q2.w, q3.x, 1.0f);
+						} else {
+							through = true;
+						}
+					}
+					if (through) {   // lit catcher = fully transparent: same depth, next pass (renderer.cpp:513-519, shading_worker.cpp:95-104)
+						const float4 q3 = qin[3 * kChunk + target];
+						if (((__float_as_uint(q3.y) & 0xFFFFu) + 1u) > 4096u) {
+							const float4 q2 = qin[2 * kChunk + target];
+							B.sample_rad[id] = make_float4(q2.z, q2.w, q3.x, 1.0f);
+							through = false;
+						}
+					}
+					const uint64_t tm = __ballot(through);
+					if (through) {
+						const uint32_t pos = n_out + __builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0u));
+						const float4 q1 = qin[kChunk + target], q2 = qin[2 * kChunk + target], q3 = qin[3 * kChunk + target];
+						const V3 dn = normalize(mk(q1.x, q1.y, q1.z));
+						qout[pos] = make_float4(x.x, x.y, x.z, __uint_as_float(id));
+						qout[kChunk + pos] = make_float4(dn.x, dn.y, dn.z, q1.w);
+						qout[2 * kChunk + pos] = q2;
+						qout[3 * kChunk + pos] = make_float4(q3.x, __uint_as_float(__float_as_uint(q3.y) + 1u), 0.f, 0.f);
+					}
+					n_out += (uint32_t)__popcll(tm);
+				}
+				rays += n_sh > lane ? (n_sh - lane + 63u) / 64u : 0u;
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			}
+			n_in = n_out;
 		}
 	}
 	// ray counter: one atomic per wave

@@ -16,7 +16,7 @@ constexpr int kBlock = PTX_BLOCK;  // threads per workgroup (one workgroup per C
 #endif
 constexpr uint32_t kChunk = PTX_CHUNK; // camera paths a wave takes per counter fetch (16 wave-iterations)
 // wave-private stream space, in float4
-constexpr uint32_t kQueueFloat4PerWave = 19u * kChunk;  // 2 x 4 ray arrays + hit records (9), the rest: hit distances + deferred-model lists
+constexpr uint32_t kQueueFloat4PerWave = 22u * kChunk;  // 2 x 4 ray arrays + hit records (9), hit distances (1/4), shadow requests (3), the rest: deferred-model lists
 constexpr uint32_t kSpillWords = 24u * 64u;  // uint2 per wave: kSpillStack levels x 64 lanes
 
 // Device view of a FlatScene (all pointers are device pointers).
