@@ -775,8 +775,11 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 						const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
 						const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
 						camera_ray(S, P, px, py, P.sample0 + s_local, o, d);
+						// a fresh path: T = 1, L = 0, depth = pass = 0; its RNG key (pixel, sample) travels with it (no divisions per vertex)
 						qin[i] = make_float4(o.x, o.y, o.z, __uint_as_float(id));
 						qin[kChunk + i] = make_float4(d.x, d.y, d.z, 1.0f);
+						qin[2 * kChunk + i] = make_float4(1.0f, 1.0f, 0.f, 0.f);
+						qin[3 * kChunk + i] = make_float4(0.f, __uint_as_float(0u), __uint_as_float(py * P.W + px), __uint_as_float(P.sample0 + s_local));
 					} else {
 						float4 q0 = qin[i], q1 = qin[kChunk + i];
 						o = mk(q0.x, q0.y, q0.z);
@@ -872,25 +875,22 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 				const bool active = i < n_in;
 				V3 o = {0, 0, 0}, d = {0, 0, 1}, T = {1, 1, 1}, L = {0, 0, 0};
 				uint32_t id = 0, depth = ALPHA ? 0u : step, pass = 0;
+				float key_px = 0.f, key_s = 0.f;   // RNG key words, carried as raw bits
 				int state = V_DEAD;
 				ShadowReq rq;
 				rq.kind = REQ_NONE;
 				if (active) {
 					PROF(9);
-					float4 q0 = qin[i], q1 = qin[kChunk + i], hq = hbuf[i];
+					const float4 q0 = qin[i], q1 = qin[kChunk + i], q2 = qin[2 * kChunk + i], q3 = qin[3 * kChunk + i], hq = hbuf[i];
 					o = mk(q0.x, q0.y, q0.z); id = __float_as_uint(q0.w);
 					d = mk(q1.x, q1.y, q1.z);
-					if (step != 0) {
-						float4 q2 = qin[2 * kChunk + i], q3 = qin[3 * kChunk + i];
-						T = mk(q1.w, q2.x, q2.y);
-						L = mk(q2.z, q2.w, q3.x);
-						if constexpr (ALPHA) { const uint32_t dp = __float_as_uint(q3.y); depth = dp >> 16; pass = dp & 0xFFFFu; }
-					}
+					T = mk(q1.w, q2.x, q2.y);
+					L = mk(q2.z, q2.w, q3.x);
+					key_px = q3.z; key_s = q3.w;
+					if constexpr (ALPHA) { const uint32_t dp = __float_as_uint(q3.y); depth = dp >> 16; pass = dp & 0xFFFFu; }
 					SceneHit h;
 					h.dist = 0; h.surface = __float_as_int(hq.x); h.tri = __float_as_uint(hq.y); h.b1 = hq.z; h.b2 = hq.w;
-					const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
-					const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
-					state = shade_vertex<SUN, ALPHA, TEX, WORKER>(S, g, st.shade, P, py * P.W + px, P.sample0 + s_local, depth, pass, h, o, d, T, L, rq);
+					state = shade_vertex<SUN, ALPHA, TEX, WORKER>(S, g, st.shade, P, __float_as_uint(key_px), __float_as_uint(key_s), depth, pass, h, o, d, T, L, rq);
 					if (state == V_DEAD) B.sample_rad[id] = make_float4(L.x, L.y, L.z, 1.0f);
 				}
 				const bool alive = state == V_ALIVE;
@@ -900,7 +900,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 					qout[pos] = make_float4(o.x, o.y, o.z, __uint_as_float(id));
 					qout[kChunk + pos] = make_float4(d.x, d.y, d.z, T.x);
 					qout[2 * kChunk + pos] = make_float4(T.y, T.z, L.x, L.y);
-					qout[3 * kChunk + pos] = make_float4(L.z, __uint_as_float((depth << 16) | pass), 0.f, 0.f);
+					qout[3 * kChunk + pos] = make_float4(L.z, __uint_as_float((depth << 16) | pass), key_px, key_s);
 				}
 				n_out += (uint32_t)__popcll(mask);
 				if constexpr (SUN) {
@@ -915,7 +915,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 						sreq[2 * kChunk + sp] = make_float4(rq.x.x, rq.x.y, rq.x.z, __uint_as_float(id));
 						if (rq.kind == REQ_CATCHER) {   // the pass-through entry is built from the current one: make its path state complete
 							qin[2 * kChunk + i] = make_float4(T.y, T.z, L.x, L.y);
-							qin[3 * kChunk + i] = make_float4(L.z, __uint_as_float((depth << 16) | pass), 0.f, 0.f);
+							qin[3 * kChunk + i] = make_float4(L.z, __uint_as_float((depth << 16) | pass), key_px, key_s);
 						}
 					}
 					n_sh += (uint32_t)__popcll(sm);
@@ -971,7 +971,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 						qout[pos] = make_float4(x.x, x.y, x.z, __uint_as_float(id));
 						qout[kChunk + pos] = make_float4(dn.x, dn.y, dn.z, q1.w);
 						qout[2 * kChunk + pos] = q2;
-						qout[3 * kChunk + pos] = make_float4(q3.x, __uint_as_float(__float_as_uint(q3.y) + 1u), 0.f, 0.f);
+						qout[3 * kChunk + pos] = make_float4(q3.x, __uint_as_float(__float_as_uint(q3.y) + 1u), q3.z, q3.w);
 					}
 					n_out += (uint32_t)__popcll(tm);
 				}
