@@ -90,37 +90,7 @@ struct Tables {
 	const uint32_t* model_space;
 };
 
-// geometry::aabb::intersect — geometry/aabb.cpp:41-67
-DEV bool aabb_test(const float* mn, const float* mx, V3 o, V3 d, float& nr, float& fr) {
-	if (mn[0] > mx[0] || mn[1] > mx[1] || mn[2] > mx[2]) return false;
-	float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
-	float ax = (mn[0] - o.x) * ix, ay = (mn[1] - o.y) * iy, az = (mn[2] - o.z) * iz;
-	float bx = (mx[0] - o.x) * ix, by = (mx[1] - o.y) * iy, bz = (mx[2] - o.z) * iz;
-	nr = pmax(pmax(pmin(ax, bx), pmin(ay, by)), pmin(az, bz));
-	fr = pmin(pmin(pmax(ax, bx), pmax(ay, by)), pmax(az, bz));
-	if (nr > fr) return false;
-	return fr >= 0;
-}
-
-// geometry::triangle::intersect — geometry/triangle.cpp:120-190 (Cramer's rule, no culling, +-epsilon slack)
-DEV float tri_test(V3 a, V3 b, V3 c, V3 o, V3 d, float& alpha, float& beta, float& gamma) {
-	V3 mx = a - b, my = a - c, v = a - o;
-	float c1 = my.y * d.z - d.y * my.z;
-	float c2 = mx.y * d.z - d.y * mx.z;
-	float c3 = mx.y * my.z - my.y * mx.z;
-	float c4 = v.y * d.z - d.y * v.z;
-	float c5 = mx.y * v.z - v.y * mx.z;
-	float c6 = my.y * v.z - v.y * my.z;
-	float inv_det = 1.0f / (mx.x * c1 - my.x * c2 + d.x * c3);
-	beta = inv_det * (v.x * c1 - my.x * c4 - d.x * c6);
-	if (beta < 0 - kEps || beta > 1 + kEps) return -1.0f;
-	gamma = inv_det * (mx.x * c4 - v.x * c2 + d.x * c5);
-	if (gamma < 0 - kEps || gamma + beta > 1 + kEps) return -1.0f;
-	float dist = inv_det * (mx.x * c6 - my.x * c5 + v.x * c3);
-	alpha = 1 - beta - gamma;
-	return dist;
-}
-
+// geometry::triangle::intersect — geometry/triangle.cpp:120-190 (Cramer's rule, no culling, +-epsilon slack).
 // The same solve from a TriIsect record (e1 = a-b, e2 = a-c and c3 precomputed with identical float operations), written
 // on 2-wide vectors so that it compiles to packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32, operands swizzled with
 // op_sel): every product and every sum is the reference's IEEE operation on the reference's operands, two at a time.
