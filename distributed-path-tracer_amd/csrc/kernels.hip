@@ -77,6 +77,10 @@ struct Geom {
 	const uint2* nodes;
 	const uint32_t* refs;
 	const float4* tris;   // TriIsect records, three float4 each (flat_scene.hpp)
+	// true (global-memory kernels): `tris` holds one record per LEAF REFERENCE, in leaf order, with the triangle id in its
+	// spare word — a leaf's records are contiguous and the refs -> record indirection (a second dependent fetch from
+	// L2/HBM per triangle) disappears. false (LDS kernels): one record per triangle, reached through `refs`.
+	bool leaf_ordered;
 };
 
 // The small per-model / per-surface tables are read with a wave-uniform index. They are passed to the kernels as
@@ -226,11 +230,11 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, 
 		uint32_t best_tri = 0;
 		for (uint32_t i = 0; i < count; i++) {
 			PROF(PB + 3);
-			const uint32_t ti = g.refs[first_ref + i];
-			const float4 r0 = g.tris[3 * ti], r1 = g.tris[3 * ti + 1];
-			const float2 r2 = *reinterpret_cast<const float2*>(&g.tris[3 * ti + 2]);
+			const uint32_t slot = g.leaf_ordered ? first_ref + i : g.refs[first_ref + i];
+			const float4 r0 = g.tris[3 * slot], r1 = g.tris[3 * slot + 1], r2 = g.tris[3 * slot + 2];
+			const uint32_t ti = g.leaf_ordered ? __float_as_uint(r2.z) : slot;
 			float be, ga;
-			const float t = tri_test_pk(r0, r1, r2, pr, be, ga);
+			const float t = tri_test_pk(r0, r1, make_float2(r2.x, r2.y), pr, be, ga);
 			if (t >= 0 && t <= max_dist && (t < best_t || !(best_t >= 0))) { best_t = t; bb1 = be; bb2 = ga; best_tri = ti; }
 		}
 		if (!(best_t >= 0)) continue;
@@ -664,7 +668,7 @@ struct Staged { Geom g; const ShadeRec* shade; };
 
 template <bool LDS>
 DEV Staged stage_geometry(const DevScene& S, unsigned char* smem) {
-	if constexpr (!LDS) return {{S.nodes, S.refs, S.tri_isect}, S.shade};
+	if constexpr (!LDS) return {{S.nodes, S.refs, S.tri_isect, true}, S.shade};   // tri_isect: leaf-ordered copy (upload_scene)
 	else {
 		// [triangle records][shade records][KD nodes][leaf refs], each region a multiple of 16 B
 		uint4* dst = reinterpret_cast<uint4*>(smem);
@@ -681,7 +685,7 @@ DEV Staged stage_geometry(const DevScene& S, unsigned char* smem) {
 		for (uint32_t i = threadIdx.x; i < n_node16; i += blockDim.x) d_n[i] = src_n[i];
 		for (uint32_t i = threadIdx.x; i < n_ref16; i += blockDim.x) d_r[i] = src_r[i];
 		__syncthreads();
-		return {{reinterpret_cast<const uint2*>(d_n), reinterpret_cast<const uint32_t*>(d_r), reinterpret_cast<const float4*>(dst)},
+		return {{reinterpret_cast<const uint2*>(d_n), reinterpret_cast<const uint32_t*>(d_r), reinterpret_cast<const float4*>(dst), false},
 		        reinterpret_cast<const ShadeRec*>(d_s)};
 	}
 }

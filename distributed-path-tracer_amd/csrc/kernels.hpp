@@ -27,7 +27,7 @@ struct DevScene {
 	const uint2* nodes;
 	const uint32_t* refs;
 	const float4* tris;   // 3 per triangle: corners + vertex ids (TriRec)
-	const float4* tri_isect; // 3 per triangle: intersection form (TriIsect)
+	const float4* tri_isect; // TriIsect records: one per triangle (LDS-resident scenes) or one per leaf reference in leaf order, id in word 10 (others)
 	const float4* vattr;  // 2 per vertex
 	const ShadeRec* shade; // 1 per surface
 	const SpaceRec* spaces; // distinct world->local transforms

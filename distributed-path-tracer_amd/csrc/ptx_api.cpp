@@ -92,7 +92,21 @@ int upload_scene(ptx_scene* sc) {
 	HIP_TRY(up(sc->d_nodes, h.kd_nodes.data(), h.kd_nodes.size() * 8, pad16(h.kd_nodes.size() * 8)));
 	HIP_TRY(up(sc->d_refs, h.kd_refs.data(), h.kd_refs.size() * 4, pad16(h.kd_refs.size() * 4)));
 	HIP_TRY(up(sc->d_tris, h.tris.data(), h.tris.size() * 48, h.tris.size() * 48));
-	HIP_TRY(up(sc->d_isect, h.tri_isect.data(), h.tri_isect.size() * 48, h.tri_isect.size() * 48));
+	sc->lds_bytes = h.tris.size() * 48 + h.shade.size() * sizeof(ShadeRec) + pad16(h.kd_nodes.size() * 8) + pad16(h.kd_refs.size() * 4);
+	sc->lds = sc->lds_bytes <= kLdsBudget;
+	if (sc->lds) {
+		HIP_TRY(up(sc->d_isect, h.tri_isect.data(), h.tri_isect.size() * 48, h.tri_isect.size() * 48));
+	} else {
+		// geometry stays in L2/HBM: one record per leaf reference, in leaf order, so that a leaf's triangles are one
+		// contiguous run and the reference -> record indirection is gone (Geom::leaf_ordered)
+		std::vector<TriIsect> leaf(h.kd_refs.size());
+		for (size_t r = 0; r < leaf.size(); r++) {
+			leaf[r] = h.tri_isect[h.kd_refs[r]];
+			memcpy(&leaf[r].p0, &h.kd_refs[r], 4);
+		}
+		HIP_TRY(up(sc->d_isect, leaf.data(), leaf.size() * 48, leaf.size() * 48));
+		HIP_TRY(hipStreamSynchronize(c->stream));   // `leaf` is about to go out of scope
+	}
 	HIP_TRY(up(sc->d_vattr, h.vattr.data(), h.vattr.size() * 32, h.vattr.size() * 32));
 	HIP_TRY(up(sc->d_shade, h.shade.data(), h.shade.size() * sizeof(ShadeRec), h.shade.size() * sizeof(ShadeRec)));
 	HIP_TRY(up(sc->d_tex, h.textures.data(), h.textures.size() * sizeof(TexRec), h.textures.size() * sizeof(TexRec)));
@@ -130,8 +144,6 @@ int upload_scene(ptx_scene* sc) {
 	d.n_tris = (uint32_t)h.tris.size();
 	d.cam = h.camera;
 	d.sun = h.sun;
-	sc->lds_bytes = h.tris.size() * 48 + h.shade.size() * sizeof(ShadeRec) + pad16(h.kd_nodes.size() * 8) + pad16(h.kd_refs.size() * 4);
-	sc->lds = sc->lds_bytes <= kLdsBudget;
 	return PTX_OK;
 }
 
