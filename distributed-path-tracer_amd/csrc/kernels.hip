@@ -399,16 +399,20 @@ DEV float fresnel_schlick(V3 outcoming, V3 incoming, float ior) {  // core/pbr.c
 	f0 *= f0;
 	return lerpf(f0, 1, pow5(1 - cos_theta));
 }
-DEV V3 importance_diffuse(float u1, float u2, V3 normal) {  // core/pbr.cpp:71-77
-	float theta = acosf(2 * u1 - 1) * 0.5F;
-	return rand_cone_vec(u2, cosf(theta), normal);
-}
-DEV V3 importance_specular(float u1, float u2, V3 normal, V3 outcoming, float roughness) {  // core/pbr.cpp:79-91
-	roughness *= roughness;
-	roughness *= roughness;
-	float cos_theta = sqrtf((1 - u1) / (1 + (roughness - 1) * u1));
-	V3 halfway = rand_cone_vec(u2, cos_theta, normal);
-	return reflect3(-outcoming, halfway);
+// pbr::importance_diffuse (core/pbr.cpp:71-77) and pbr::importance_specular (:79-91) differ in the cone angle they hand to
+// rand_cone_vec and in the final reflection; the cone construction itself (sin / cos of the azimuth, tangent frame) is the
+// same code — run it once for the whole wave instead of once per lobe under complementary lane masks.
+DEV V3 importance_sample(bool specular, float u1, float u2, V3 normal, V3 outcoming, float roughness) {
+	float cos_theta;
+	if (specular) {
+		roughness *= roughness;
+		roughness *= roughness;
+		cos_theta = sqrtf((1 - u1) / (1 + (roughness - 1) * u1));
+	} else {
+		cos_theta = cosf(acosf(2 * u1 - 1) * 0.5F);
+	}
+	const V3 h = rand_cone_vec(u2, cos_theta, normal);
+	return specular ? reflect3(-outcoming, h) : h;
 }
 DEV float smith_g1(V3 n, V3 l, float k) { float c = dot(n, l); return c / pmax(lerpf(k, 1, c), kEps); }  // pbr.cpp:95-102
 DEV float pdf_diffuse(V3 n, V3 i) { return (float)((double)dot(n, i) / kPi); }                           // pbr.cpp:118-123
@@ -635,8 +639,7 @@ DEV int shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, co
 			rq.x = T * direct_out;
 		}
 	}
-	const V3 inc = (rnd.y < spec_prob) ? importance_specular(rnd.z, rnd.w, normal, outcoming, roughness)
-	                                    : importance_diffuse(rnd.z, rnd.w, normal);
+	const V3 inc = importance_sample(rnd.y < spec_prob, rnd.z, rnd.w, normal, outcoming, roughness);
 	if constexpr (!WORKER) L = L + T * me.emissive10;
 	if (!(dot(normal, inc) > 0)) return V_DEAD;                              // renderer.cpp:578 / shading_worker.cpp:154,196-199
 	float pdf;
