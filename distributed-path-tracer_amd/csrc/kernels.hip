@@ -382,7 +382,14 @@ DEV V3 shading_normal(const Surf& s, V3 nts) {
 DEV V3 rand_cone_vec(float rnd, float cos_theta, V3 normal) {
 	float phi = (float)((double)(rnd * 2) * kPi);
 	float sin_theta = sqrtf(1 - cos_theta * cos_theta);
-	V3 cone = {cosf(phi) * sin_theta, sinf(phi) * sin_theta, cos_theta};
+	float sp, cp;
+#ifdef PTX_SEPARATE_SINCOS
+	sp = sinf(phi); cp = cosf(phi);
+#else
+	sincosf(phi, &sp, &cp);   // one argument reduction for both (ocml evaluates sinf / cosf through the same reduced kernels:
+	                          // images are bit-identical to the two separate calls — checked with a -DPTX_SEPARATE_SINCOS build)
+#endif
+	V3 cone = {cp * sin_theta, sp * sin_theta, cos_theta};
 	V3 np = {0, 0, 0};
 	if ((double)fabsf(normal.x) < kInvSqrt3) np.x = 1;
 	else if ((double)fabsf(normal.y) < kInvSqrt3) np.y = 1;
