@@ -42,6 +42,18 @@ def measured_traffic():
         return json.load(fh).get("traffic_bytes_per_launch")
 
 
+def measured_valu():
+    """VALU issue-slot occupancy of the dominant kernel from the committed PMC profile (the resource that actually binds it:
+    DESIGN.md "Roofline accounting"). None if no profile."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_valu.json")))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        v = json.load(fh)
+    return {"valu_issue_frac": v.get("valu_issue_frac"), "lane_utilisation": v.get("lane_utilisation")}
+
+
 def cpu_baseline():
     """Time the reference's own renderer::render on the host cores: 1080p, 8 bounces, 1 spp (~10 s)."""
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
@@ -74,6 +86,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel per GPU per step (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", choices=("samples", "tiles"), default="samples",
+                    help="samples: every rank traces --spp samples of every pixel (weak scaling, the default); "
+                         "tiles: ONE --spp frame split into row bands across ranks (strong scaling)")
     args = ap.parse_args()
 
     import numpy as np
@@ -101,7 +116,10 @@ def main():
         accum.zero_()
         torch.cuda.synchronize()
         # this rank's sample range -> ptx_render (syncs the ctx stream) -> RCCL sum-reduce of the framebuffer onto rank 0
-        st = mg.render_sharded(scene, W, H, spp, BOUNCES, accum, rank, world, want_stats=True)
+        if args.shard == "tiles":
+            st = mg.render_tiles(scene, W, H, spp, BOUNCES, accum, rank, world, want_stats=True)
+        else:
+            st = mg.render_sharded(scene, W, H, spp, BOUNCES, accum, rank, world, want_stats=True)
         if collect is not None:
             collect.append(st)
 
@@ -130,7 +148,8 @@ def main():
         total_rays = float(sum(s["rays"] for s in stats))
 
     if rank == 0:
-        samples = float(W) * H * spp * world * args.steps
+        weak = args.shard == "samples"
+        samples = float(W) * H * spp * (world if weak else 1) * args.steps
         launches = sum(s["passes"] for s in stats)
         kernel_ms = sum(s["kernel_ms"] for s in stats) / max(launches, 1)     # average launch of k_render_pass (HIP events)
         rays_per_launch = sum(s["rays"] for s in stats) / max(launches, 1)
@@ -139,17 +158,21 @@ def main():
             "metric": "Msamples/sec, Cornell box 1920x1080, 256 spp, 8 bounces (camera paths traced per second)",
             "value": round(samples / dt / 1e6, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Cornell box (scenes/cornell-box/cornell.gltf) {W}x{H}, {spp} spp per GPU, {BOUNCES} bounces, "
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Cornell box (scenes/cornell-box/cornell.gltf) {W}x{H}, {spp} spp per {'GPU' if weak else 'frame'}, {BOUNCES} bounces, "
                                    f"1xMI355X per rank (BASELINE.json configs[1])",
-                       "spp_total": spp * world, "sharding": "sample ranges per rank + RCCL sum-reduce of the accumulation buffer" if world > 1 else "none"},
+                       "spp_total": spp * world if weak else spp,
+                       "sharding": "none" if world == 1 else ("sample ranges per rank" if weak else "row bands per rank") + " + RCCL sum-reduce of the accumulation buffer"},
             "mrays_per_s": round(total_rays / dt / 1e6, 2),
             "rays_per_sample": round(total_rays / samples, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(),
                          "algorithmic_bytes_per_launch": round(rays_per_launch * B_RAY_CORNELL),
                          "kernel": "k_render_pass<LDS>", "avg_launch_ms": round(kernel_ms, 4), "launches": launches,
-                         "rays_per_launch": round(rays_per_launch), "bytes_per_ray": round(B_RAY_CORNELL, 2)},
+                         "rays_per_launch": round(rays_per_launch), "bytes_per_ray": round(B_RAY_CORNELL, 2),
+                         # algorithmic bytes count the geometry fetches that LDS serves, so `frac` can exceed what HBM sees
+                         # (`traffic`); the binding resource is VALU issue — from the same PMC profile:
+                         "binding": measured_valu()},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -21,8 +21,8 @@ class OracleScene:
     def __init__(self):
         self.s = ora.OracleScene(ora.load_gltf(CORNELL))
 
-    def render(self, W, H, spp, bounces, accum=None, sample0=0, **kw):
-        smp = self.s.render_samples(ora.make_cfg(W, H, spp, bounces, sample0=sample0), threads=2)   # [H,W,spp,3]
+    def render(self, W, H, spp, bounces, accum=None, sample0=0, tile=None, **kw):
+        smp = self.s.render_samples(ora.make_cfg(W, H, spp, bounces, sample0=sample0, tile=tile), threads=2)   # [h,w,spp,3]
         a = accum.numpy()
         for k in range(spp):                       # sums in sample order, like k_resolve
             a[..., :3] += smp[:, :, k]
@@ -32,11 +32,15 @@ class OracleScene:
 
 def main():
     out = sys.argv[1]
+    mode = sys.argv[2] if len(sys.argv) > 2 else "samples"
     W, H, spp, b = 40, 24, 3, 4
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     accum = torch.zeros((H, W, 4), dtype=torch.float32)
-    mg.render_sharded(OracleScene(), W, H, spp, b, accum, rank, world)
+    if mode == "tiles":
+        mg.render_tiles(OracleScene(), W, H, 2 * spp, b, accum, rank, world)
+    else:
+        mg.render_sharded(OracleScene(), W, H, spp, b, accum, rank, world)
     if rank == 0:
         np.save(out, accum.numpy())
     dist.barrier()

@@ -19,6 +19,11 @@ def test_sample_partitions():
             assert sum(n for _, n in parts) == total
             assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(world - 1))   # contiguous, disjoint
             assert max(n for _, n in parts) - min(n for _, n in parts) <= 1
+        for H in (0, 1, 7, 1080, 2160):
+            bands = [mg.tile_rows(r, world, H) for r in range(world)]
+            assert sum(h for _, h in bands) == H and bands[0][0] == 0
+            assert all(bands[i][0] + bands[i][1] == bands[i + 1][0] for i in range(world - 1))
+            assert max(h for _, h in bands) - min(h for _, h in bands) <= 1
     with pytest.raises(ValueError):
         mg.sample_range(2, 2, 4)
 
@@ -40,3 +45,21 @@ def test_two_rank_framebuffer_reduce_equals_single_rank(tmp_path, cornell_oracle
     np.testing.assert_array_equal(got[..., 3], ref[..., 3])
     # (s0+s1+s2) + (s3+s4+s5) vs ((((s0+s1)+s2)+s3)+s4)+s5: equal up to float32 summation order
     np.testing.assert_allclose(got[..., :3], ref[..., :3], rtol=2e-6, atol=1e-6)
+
+
+def test_two_rank_tile_sharding_is_bitwise_the_single_rank_frame(tmp_path, cornell_oracle, ora):
+    """Strong scaling: two ranks render the two halves of one frame; the sum-reduce of (band, zeros) assembles exactly the frame."""
+    out = str(tmp_path / "tiles.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(ROOT, "tests", "_dist_worker.py"), out, "tiles"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out)
+    W, H, spp, b = 40, 24, 6, 4
+    smp = cornell_oracle.render_samples(ora.make_cfg(W, H, spp, b), threads=4)
+    ref = np.zeros((H, W, 4), np.float32)
+    for k in range(spp):
+        ref[..., :3] += smp[:, :, k]
+        ref[..., 3] += 1.0
+    np.testing.assert_array_equal(got, ref)
