@@ -198,6 +198,15 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, 
 		while ((nd.y & 3u) != KD_LEAF) {
 			PROF(PB + 2);
 			uint32_t axis = nd.y & 3u;
+			// global-memory trees: both children (adjacent, 16 bytes) are requested as soon as the parent arrives, so the
+			// split arithmetic below (an IEEE division) runs under the fetch instead of before it
+			uint2 kid0 = make_uint2(0, 0), kid1 = make_uint2(0, 0);
+#ifndef PTX_NO_PAIR_FETCH
+			constexpr bool pair_fetch = true;
+#else
+			constexpr bool pair_fetch = false;
+#endif
+			if (pair_fetch && g.leaf_ordered) { kid0 = g.nodes[nd.y >> 4]; kid1 = g.nodes[(nd.y >> 4) + 1u]; }
 			float split = __uint_as_float(nd.x);
 			float oa = sel3(o, axis), da = sel3(d, axis);
 			float split_dist = (split - oa) / da;
@@ -221,7 +230,7 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, 
 			}
 			if (!has_next) { valid = false; break; }
 			node = next;
-			nd = g.nodes[node];
+			nd = (pair_fetch && g.leaf_ordered) ? (next == li ? kid0 : kid1) : g.nodes[node];
 		}
 		if (!valid) continue;
 		// leaf: nearest triangle with t <= max_dist; ties keep the first (mesh.cpp:381-389)
