@@ -57,8 +57,9 @@ static_assert(sizeof(ModelRec) == 41 * 4, "ModelRec layout");
 // ---- per-surface record (model::surface = mesh + material) ----
 struct SurfaceRec {
 	float bmin[3], bmax[3];  // mesh AABB (mesh.cpp:254-261)
-	uint32_t kd_root;        // index of the root KD node
+	uint32_t kd_root;        // index of the root KD node in the full node array
 	uint32_t tri_base;       // global id of the mesh's triangle 0
+	uint32_t lds_root;       // index of the root in the LDS-resident node array, 0xFFFFFFFF when the surface is not resident
 };
 
 // ---- material factors (core/material.hpp:11-17) and texture slots ----
@@ -131,8 +132,19 @@ struct FlatScene {
 	bool any_texture = false;
 	bool any_alpha = false;              // some material can take the opacity / shadow-catcher pass-through branch
 
+	// LDS residency plan (plan_residency): the traversal arrays of the surfaces that fit one CU's LDS, indices local to them
+	std::vector<KdNode> res_nodes;
+	std::vector<uint32_t> res_refs;      // indices into res_tris
+	std::vector<TriIsect> res_tris;      // p0 = global triangle id
+	uint32_t n_resident = 0;             // surfaces with SurfaceRec::lds_root valid
+	size_t res_bytes = 0;                // LDS bytes the resident arrays + shade records take
+
 	size_t geometry_bytes() const { return kd_nodes.size() * 8 + kd_refs.size() * 4 + tris.size() * 48; }
 };
+
+// Chooses which surfaces are staged into LDS (smallest first, while they fit `lds_budget` together with the shade records)
+// and builds their compact arrays; sets SurfaceRec::lds_root. All surfaces resident => the compact arrays equal the full ones.
+void plan_residency(FlatScene& s, size_t lds_budget);
 
 // Builds everything derived (AABBs, KD-trees, records) from the "as loaded" arrays + camera/sun floats.
 // camera13: origin(3) basis(9) fov ; sun13: basis(9) energy(3) angular_radius or nullptr.

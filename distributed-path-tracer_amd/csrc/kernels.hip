@@ -82,6 +82,9 @@ struct Geom {
 	// L2/HBM per triangle) disappears. false (LDS kernels): one record per triangle, reached through `refs`.
 	bool leaf_ordered;
 };
+// Both copies a kernel may traverse (kernels.hpp: MODE_GLOBAL / MODE_LDS / MODE_HYBRID); in MODE_HYBRID the branch between
+// them is wave-uniform (the surface index is).
+struct Geoms { Geom lds, glb; };
 
 // The small per-model / per-surface tables are read with a wave-uniform index. They are passed to the kernels as
 // separate `const T* __restrict__` arguments (not inside DevScene): only then can the compiler prove that the
@@ -171,7 +174,7 @@ DEV bool aabb_test_inv(const float* mn, const float* mx, V3 o, V3 inv, float& nr
 // min_dist of the entry beneath it (each push hands its old max_dist to the pushed subtree and continues
 // with max_dist = split_dist = the pushed min_dist), and the AABB exit distance for the bottom one.
 template <int PB>
-DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, MeshHit& out, const Spill& spill PROF_ARG) {
+DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, uint32_t root, V3 o, V3 d, V3 inv, MeshHit& out, const Spill& spill PROF_ARG) {
 	PROF(PB);
 	float nr, fr;
 	if (!aabb_test_inv(sf.bmin, sf.bmax, o, inv, nr, fr)) return false;
@@ -179,7 +182,7 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, 
 	int sp = 0;
 	uint32_t n0 = 0, n1 = 0, n2 = 0;  // register stack: entry 0 is the top
 	float m0 = 0, m1 = 0, m2 = 0;
-	uint32_t node = sf.kd_root;
+	uint32_t node = root;
 	float min_dist = nr, max_dist = fr;
 	bool have = true;
 	for (;;) {
@@ -241,7 +244,7 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, 
 			PROF(PB + 3);
 			const uint32_t slot = g.leaf_ordered ? first_ref + i : g.refs[first_ref + i];
 			const float4 r0 = g.tris[3 * slot], r1 = g.tris[3 * slot + 1], r2 = g.tris[3 * slot + 2];
-			const uint32_t ti = g.leaf_ordered ? __float_as_uint(r2.z) : slot;
+			const uint32_t ti = __float_as_uint(r2.z);   // global triangle id, carried by every record
 			float be, ga;
 			const float t = tri_test_pk(r0, r1, make_float2(r2.x, r2.y), pr, be, ga);
 			if (t >= 0 && t <= max_dist && (t < best_t || !(best_t >= 0))) { best_t = t; bb1 = be; bb2 = ga; best_tri = ti; }
@@ -252,12 +255,24 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, V3 o, V3 d, V3 inv, 
 	}
 }
 
+// core::mesh::intersect on whichever copy of the surface's tree the scene's MODE prescribes
+template <int MODE, int PB>
+DEV bool mesh_traverse_m(const Geoms& G, const SurfaceRec& sf, V3 o, V3 d, V3 inv, MeshHit& out, const Spill& spill PROF_ARG) {
+	if constexpr (MODE == MODE_GLOBAL) return mesh_traverse<PB>(G.glb, sf, sf.kd_root, o, d, inv, out, spill PROF_PASS);
+	else if constexpr (MODE == MODE_LDS) return mesh_traverse<PB>(G.lds, sf, sf.lds_root, o, d, inv, out, spill PROF_PASS);
+	else {
+		if (sf.lds_root != 0xFFFFFFFFu) return mesh_traverse<PB>(G.lds, sf, sf.lds_root, o, d, inv, out, spill PROF_PASS);
+		return mesh_traverse<PB>(G.glb, sf, sf.kd_root, o, d, inv, out, spill PROF_PASS);
+	}
+}
+
 // Closest hit record: what the shading phase needs to rebuild everything else.
 // alpha is not stored: it is 1 - beta - gamma (triangle.cpp:185), recomputed with the same two subtractions.
 struct SceneHit { float dist; int surface; uint32_t tri; float b1, b2; };
 
 // renderer::intersect (core/renderer.cpp:645-671) over scene::model::intersect (scene/model.cpp:20-72)
-DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& best, const Spill& spill) {
+template <int MODE>
+DEV bool scene_traverse(const DevScene& S, const Geoms& g, V3 o, V3 d, SceneHit& best, const Spill& spill) {
 #ifdef PTX_PROF
 	Prof prof{};   // not reported: only the EXTEND sweeps of k_render_pass are profiled
 #endif
@@ -284,7 +299,7 @@ DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& 
 		int hit_surface = -1;
 		for (int s = 0; s < M.n_surfaces; s++) {
 			MeshHit h;
-			if (!mesh_traverse<4>(g, S.surfaces[M.first_surface + s], lo, ld, inv, h, spill PROF_PASS)) continue;
+			if (!mesh_traverse_m<MODE, 4>(g, S.surfaces[M.first_surface + s], lo, ld, inv, h, spill PROF_PASS)) continue;
 			if (h.t < nearest.t || !(nearest.t >= 0)) { nearest = h; hit_surface = M.first_surface + s; }
 		}
 		if (!(nearest.t >= 0)) continue;
@@ -311,7 +326,8 @@ DEV bool scene_traverse(const DevScene& S, const Geom& g, V3 o, V3 d, SceneHit& 
 #endif
 // renderer::intersect(shadow ray).has_hit() (renderer.cpp:509-511, intersection_worker.cpp:58-61): the reference finds the closest
 // hit and then only asks whether there is one, so the sweep may stop at the first model that reports a hit.
-DEV bool scene_occluded(const DevScene& S, const Geom& g, V3 o, V3 d, const Spill& spill) {
+template <int MODE>
+DEV bool scene_occluded(const DevScene& S, const Geoms& g, V3 o, V3 d, const Spill& spill) {
 #ifdef PTX_PROF
 	Prof prof{};
 #endif
@@ -331,7 +347,7 @@ DEV bool scene_occluded(const DevScene& S, const Geom& g, V3 o, V3 d, const Spil
 		if (!aabb_test_inv(M.bmin, M.bmax, lo, inv, nr, fr)) continue;
 		for (int s = 0; s < M.n_surfaces; s++) {
 			MeshHit h;
-			if (!mesh_traverse<4>(g, S.surfaces[M.first_surface + s], lo, ld, inv, h, spill PROF_PASS)) continue;
+			if (!mesh_traverse_m<MODE, 4>(g, S.surfaces[M.first_surface + s], lo, ld, inv, h, spill PROF_PASS)) continue;
 			if (length(mulmv(M.basis, ld * h.t)) >= 0) return true;   // model.cpp:62-63: a hit whose world distance is not NaN
 		}
 	}
@@ -343,15 +359,15 @@ constexpr uint32_t kListCap = (kChunk / 64u) * (kInlineMin - 1u) + 16u;   // ent
 constexpr int kMaxDeferModels = 64;        // per-model list lengths live in the lanes of one VGPR
 
 // Closest hit inside ONE model for a lane that is known to enter its box: scene::model::intersect (model.cpp:27-63)
-template <int PB>
-DEV bool model_traverse(const DevScene& S, const Geom& g, const ModelRec& M, V3 lo, V3 ld, V3 inv, float& wd, int& surf, uint32_t& tri,
+template <int MODE, int PB>
+DEV bool model_traverse(const DevScene& S, const Geoms& g, const ModelRec& M, V3 lo, V3 ld, V3 inv, float& wd, int& surf, uint32_t& tri,
                         float& b1, float& b2, const Spill& spill PROF_ARG) {
 	MeshHit nearest;
 	nearest.t = -1.0f;
 	int hit_surface = -1;
 	for (int k = 0; k < M.n_surfaces; k++) {
 		MeshHit h;
-		if (!mesh_traverse<PB>(g, S.surfaces[M.first_surface + k], lo, ld, inv, h, spill PROF_PASS)) continue;
+		if (!mesh_traverse_m<MODE, PB>(g, S.surfaces[M.first_surface + k], lo, ld, inv, h, spill PROF_PASS)) continue;
 		if (h.t < nearest.t || !(nearest.t >= 0)) { nearest = h; hit_surface = M.first_surface + k; }
 	}
 	if (!(nearest.t >= 0)) return false;
@@ -364,7 +380,7 @@ DEV bool model_traverse(const DevScene& S, const Geom& g, const ModelRec& M, V3 
 struct Surf { V3 pos, nrm, tan; float u, v; };
 
 // attribute interpolation of renderer::intersect — core/renderer.cpp:688-715
-DEV void hit_attributes(const DevScene& S, const Geom& g, const ShadeRec& R, uint32_t tri, float b1, float b2, Surf& out) {
+DEV void hit_attributes(const DevScene& S, const ShadeRec& R, uint32_t tri, float b1, float b2, Surf& out) {
 	const float b0 = 1 - b1 - b2;
 	const float4 A = S.tris[3 * tri], B = S.tris[3 * tri + 1], C = S.tris[3 * tri + 2];   // TriRec (global: once per hit)
 	uint32_t ia = __float_as_uint(A.w), ib = __float_as_uint(B.w), ic = __float_as_uint(C.w);
@@ -593,7 +609,7 @@ struct ShadowReq {
 // `T` cloud_ray::scale, `depth` = bounce_count - cloud_ray::bounce.
 // `h` is the closest hit of (o, d) found by the extend sweep. SUN / ALPHA compile the request / pass-through code in.
 template <bool SUN, bool ALPHA, bool TEX, bool WORKER>
-DEV int shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, const RenderParams& P, uint32_t pixel, uint32_t sample,
+DEV int shade_vertex(const DevScene& S, const ShadeRec* shade, const RenderParams& P, uint32_t pixel, uint32_t sample,
                      uint32_t& depth, uint32_t& pass, SceneHit h, V3& o, V3& d, V3& T, V3& L, ShadowReq& rq) {
 	rq.kind = REQ_NONE;
 	if (h.surface < 0) {
@@ -602,7 +618,7 @@ DEV int shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, co
 	}
 	const ShadeRec& R = shade[h.surface];
 	Surf sf;
-	hit_attributes(S, g, R, h.tri, h.b1, h.b2, sf);
+	hit_attributes(S, R, h.tri, h.b1, h.b2, sf);
 	const MaterialRec& mt = R.mat;
 	const MatEval me = material_eval<TEX>(S, mt, sf.u, sf.v);   // renderer.cpp:458-462
 	float roughness = me.roughness;
@@ -683,19 +699,21 @@ DEV int shade_vertex(const DevScene& S, const Geom& g, const ShadeRec* shade, co
 }
 
 // ------------------------------------------------------------------------------------ LDS staging
-struct Staged { Geom g; const ShadeRec* shade; };
+struct Staged { Geoms g; const ShadeRec* shade; };
 
-template <bool LDS>
+template <int MODE>
 DEV Staged stage_geometry(const DevScene& S, unsigned char* smem) {
-	if constexpr (!LDS) return {{S.nodes, S.refs, S.tri_isect, true}, S.shade};   // tri_isect: leaf-ordered copy (upload_scene)
+	const Geom glb = {S.nodes, nullptr, S.tri_isect, true};   // tri_isect: leaf-ordered records of ALL surfaces (upload_scene)
+	if constexpr (MODE == MODE_GLOBAL) return {{glb, glb}, S.shade};
 	else {
+		// the resident arrays (all surfaces in MODE_LDS, the ones that fit in MODE_HYBRID):
 		// [triangle records][shade records][KD nodes][leaf refs], each region a multiple of 16 B
 		uint4* dst = reinterpret_cast<uint4*>(smem);
-		const uint32_t n_tri16 = S.n_tris * 3, n_shade16 = S.n_surfaces * (uint32_t)(sizeof(ShadeRec) / 16), n_node16 = (S.n_nodes + 1) / 2, n_ref16 = (S.n_refs + 3) / 4;
-		const uint4* src_t = reinterpret_cast<const uint4*>(S.tri_isect);
+		const uint32_t n_tri16 = S.n_res_tris * 3, n_shade16 = S.n_surfaces * (uint32_t)(sizeof(ShadeRec) / 16), n_node16 = (S.n_res_nodes + 1) / 2, n_ref16 = (S.n_res_refs + 3) / 4;
+		const uint4* src_t = reinterpret_cast<const uint4*>(S.res_tris);
 		const uint4* src_s = reinterpret_cast<const uint4*>(S.shade);
-		const uint4* src_n = reinterpret_cast<const uint4*>(S.nodes);
-		const uint4* src_r = reinterpret_cast<const uint4*>(S.refs);
+		const uint4* src_n = reinterpret_cast<const uint4*>(S.res_nodes);
+		const uint4* src_r = reinterpret_cast<const uint4*>(S.res_refs);
 		uint4* d_s = dst + n_tri16;
 		uint4* d_n = d_s + n_shade16;
 		uint4* d_r = d_n + n_node16;
@@ -704,8 +722,8 @@ DEV Staged stage_geometry(const DevScene& S, unsigned char* smem) {
 		for (uint32_t i = threadIdx.x; i < n_node16; i += blockDim.x) d_n[i] = src_n[i];
 		for (uint32_t i = threadIdx.x; i < n_ref16; i += blockDim.x) d_r[i] = src_r[i];
 		__syncthreads();
-		return {{reinterpret_cast<const uint2*>(d_n), reinterpret_cast<const uint32_t*>(d_r), reinterpret_cast<const float4*>(dst), false},
-		        reinterpret_cast<const ShadeRec*>(d_s)};
+		const Geom lds = {reinterpret_cast<const uint2*>(d_n), reinterpret_cast<const uint32_t*>(d_r), reinterpret_cast<const float4*>(dst), false};
+		return {{lds, glb}, reinterpret_cast<const ShadeRec*>(d_s)};
 	}
 }
 
@@ -716,12 +734,12 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 // Per wave and chunk of kChunk paths, every bounce is two sweeps over the wave's private ray stream:
 //   EXTEND: (generate or) load ray -> closest hit -> 16-byte hit record        (traversal state only in registers)
 //   SHADE : load ray + hit + path state -> BSDF, radiance, next ray -> compacted write (path state only)
-template <bool LDS, bool SUN, bool ALPHA, bool TEX, bool WORKER>
+template <int MODE, bool SUN, bool ALPHA, bool TEX, bool WORKER>
 __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParams P, PassBuffers B, const ModelRec* __restrict__ t_models, const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
 	DevScene S = S0;
 	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;  // see struct Tables
-	const Staged st = stage_geometry<LDS>(S, g_smem);
-	const Geom g = st.g;
+	const Staged st = stage_geometry<MODE>(S, g_smem);
+	const Geoms g = st.g;
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave_slot = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	// wave-private streams: 2 ray buffers x 4 float4 arrays x kChunk entries, then 1 hit array
@@ -780,7 +798,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 					}
 				}
 				SceneHit h;
-				if (!defer) { if (active) scene_traverse(S, g, o, d, h, spill); }
+				if (!defer) { if (active) scene_traverse<MODE>(S, g, o, d, h, spill); }
 				else {
 					// renderer::intersect's model loop with the rarely entered models set aside
 					h.dist = -1.0f; h.surface = -1; h.tri = 0; h.b1 = 0; h.b2 = 0;
@@ -807,7 +825,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 							if (enters) {
 								PROF(3);
 								float wd, b1, b2; int surf; uint32_t tri;
-								if (model_traverse<4>(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill PROF_PASS) &&
+								if (model_traverse<MODE, 4>(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill PROF_PASS) &&
 								    (wd < h.dist || !(h.dist >= 0) || (wd == h.dist && surf < h.surface))) { h.dist = wd; h.surface = surf; h.tri = tri; h.b1 = b1; h.b2 = b2; }
 							}
 						} else {
@@ -845,7 +863,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 							const V3 lo = mk(e0.x, e0.y, e0.z), ld = mk(e1.x, e1.y, e1.z);
 							const V3 inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
 							float wd, b1, b2; int surf; uint32_t tri;
-							if (model_traverse<10>(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill PROF_PASS) &&
+							if (model_traverse<MODE, 10>(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill PROF_PASS) &&
 							    (wd < bd || !(bd >= 0) || (wd == bd && surf < bs))) {
 								hbuf[i] = make_float4(__int_as_float(surf), __uint_as_float(tri), b1, b2);
 								hdist[i] = wd;
@@ -883,7 +901,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 					if constexpr (ALPHA) { const uint32_t dp = __float_as_uint(q3.y); depth = dp >> 16; pass = dp & 0xFFFFu; }
 					SceneHit h;
 					h.dist = 0; h.surface = __float_as_int(hq.x); h.tri = __float_as_uint(hq.y); h.b1 = hq.z; h.b2 = hq.w;
-					state = shade_vertex<SUN, ALPHA, TEX, WORKER>(S, g, st.shade, P, __float_as_uint(key_px), __float_as_uint(key_s), depth, pass, h, o, d, T, L, rq);
+					state = shade_vertex<SUN, ALPHA, TEX, WORKER>(S, st.shade, P, __float_as_uint(key_px), __float_as_uint(key_s), depth, pass, h, o, d, T, L, rq);
 					if (state == V_DEAD) B.sample_rad[id] = make_float4(L.x, L.y, L.z, 1.0f);
 				}
 				const bool alive = state == V_ALIVE;
@@ -928,7 +946,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 						const float4 r0 = sreq[j], r1 = sreq[kChunk + j], r2 = sreq[2 * kChunk + j];
 						target = __float_as_uint(r0.w); id = __float_as_uint(r2.w);
 						x = mk(r2.x, r2.y, r2.z);
-						const bool occluded = scene_occluded(S, g, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), spill);
+						const bool occluded = scene_occluded<MODE>(S, g, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), spill);
 						if (__float_as_uint(r1.w) == REQ_ADD) {
 							if (!occluded) {
 								if (target == 0xFFFFFFFFu) {
@@ -999,18 +1017,18 @@ __global__ void k_resolve(const float4* __restrict__ sample_rad, float4* __restr
 }
 
 // ------------------------------------------------------------------------------------ batch intersect
-template <bool LDS>
+template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_intersect_batch(DevScene S0, IntersectArgs A, const ModelRec* __restrict__ t_models, const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
 	DevScene S = S0;
 	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;  // see struct Tables
-	const Staged st = stage_geometry<LDS>(S, g_smem);
-	const Geom g = st.g;
+	const Staged st = stage_geometry<MODE>(S, g_smem);
+	const Geoms g = st.g;
 	const Spill spill{A.spill + (size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * (kSpillStack * 64) + (threadIdx.x & 63u)};
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += stride) {
 		const V3 o = mk(A.ox[i], A.oy[i], A.oz[i]), d = mk(A.dx[i], A.dy[i], A.dz[i]);
 		SceneHit h;
-		const bool hit = scene_traverse(S, g, o, d, h, spill);
+		const bool hit = scene_traverse<MODE>(S, g, o, d, h, spill);
 		A.distance[i] = hit ? h.dist : -1.0f;
 		A.surface[i] = hit ? h.surface : -1;
 		A.triangle[i] = hit ? (int32_t)(h.tri - S.surfaces[h.surface].tri_base) : -1;
@@ -1020,7 +1038,7 @@ __global__ void __launch_bounds__(kBlock) k_intersect_batch(DevScene S0, Interse
 			V3 sn = {0, 0, 0};
 			if (hit) {
 				const ShadeRec& R = st.shade[h.surface];
-				hit_attributes(S, g, R, h.tri, h.b1, h.b2, sf);
+				hit_attributes(S, R, h.tri, h.b1, h.b2, sf);
 				sn = shading_normal(sf, material_eval<true>(S, R.mat, sf.u, sf.v).normal_ts);
 			}
 			if (A.px) { A.px[i] = sf.pos.x; A.py[i] = sf.pos.y; A.pz[i] = sf.pos.z; }
@@ -1060,54 +1078,53 @@ static hipError_t set_lds(const void* fn, size_t bytes) {
 	return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <bool LDS, bool SUN, bool ALPHA, bool TEX, bool WORKER = false>
+template <int MODE, bool SUN, bool ALPHA, bool TEX, bool WORKER = false>
 static hipError_t launch_pass_variant(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
-	if (LDS) {
-		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<LDS, SUN, ALPHA, TEX, WORKER>), lds_bytes);
+	if (MODE != MODE_GLOBAL) {
+		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<MODE, SUN, ALPHA, TEX, WORKER>), lds_bytes);
 		if (e != hipSuccess) return e;
 	}
-	hipLaunchKernelGGL((k_render_pass<LDS, SUN, ALPHA, TEX, WORKER>), dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, stream, S, P, B, S.models, S.surfaces, S.spaces, S.model_space);
+	hipLaunchKernelGGL((k_render_pass<MODE, SUN, ALPHA, TEX, WORKER>), dim3(grid), dim3(kBlock), MODE != MODE_GLOBAL ? lds_bytes : 0, stream, S, P, B, S.models, S.surfaces, S.spaces, S.model_space);
 	return hipGetLastError();
 }
 
-// Kernel variants: {geometry in LDS or not} x {sun shadow rays} x {opacity / shadow-catcher re-trace}; textured scenes get
-// one variant with everything compiled in (its sun code is still skipped at run time when the scene has no sun).
-hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, bool lds, size_t lds_bytes, int grid,
-                              hipStream_t stream) {
+// Kernel variants: {where the geometry lives} x {sun shadow rays} x {opacity / shadow-catcher pass-through}; textured scenes
+// and the worker estimator get one variant with everything compiled in (sun code is skipped at run time without a sun).
+template <int MODE>
+static hipError_t launch_pass_mode(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
 	const bool sun = S.sun.present != 0, alpha = S.any_alpha != 0;
-	if (P.integrator == 1u) {   // the HOST worker's estimator: one variant per {LDS, textures}, sun / alpha decided at run time
-		if (S.any_texture) return lds ? launch_pass_variant<true, true, true, true, true>(S, P, B, lds_bytes, grid, stream)
-		                              : launch_pass_variant<false, true, true, true, true>(S, P, B, lds_bytes, grid, stream);
-		return lds ? launch_pass_variant<true, true, true, false, true>(S, P, B, lds_bytes, grid, stream)
-		           : launch_pass_variant<false, true, true, false, true>(S, P, B, lds_bytes, grid, stream);
-	}
-	if (S.any_texture) return lds ? launch_pass_variant<true, true, true, true>(S, P, B, lds_bytes, grid, stream)
-	                              : launch_pass_variant<false, true, true, true>(S, P, B, lds_bytes, grid, stream);
-	const int v = (lds ? 4 : 0) | (sun ? 2 : 0) | (alpha ? 1 : 0);
-	switch (v) {
-	case 0: return launch_pass_variant<false, false, false, false>(S, P, B, lds_bytes, grid, stream);
-	case 1: return launch_pass_variant<false, false, true, false>(S, P, B, lds_bytes, grid, stream);
-	case 2: return launch_pass_variant<false, true, false, false>(S, P, B, lds_bytes, grid, stream);
-	case 3: return launch_pass_variant<false, true, true, false>(S, P, B, lds_bytes, grid, stream);
-	case 4: return launch_pass_variant<true, false, false, false>(S, P, B, lds_bytes, grid, stream);
-	case 5: return launch_pass_variant<true, false, true, false>(S, P, B, lds_bytes, grid, stream);
-	case 6: return launch_pass_variant<true, true, false, false>(S, P, B, lds_bytes, grid, stream);
-	default: return launch_pass_variant<true, true, true, false>(S, P, B, lds_bytes, grid, stream);
-	}
+	if (P.integrator == 1u)
+		return S.any_texture ? launch_pass_variant<MODE, true, true, true, true>(S, P, B, lds_bytes, grid, stream)
+		                     : launch_pass_variant<MODE, true, true, false, true>(S, P, B, lds_bytes, grid, stream);
+	if (S.any_texture) return launch_pass_variant<MODE, true, true, true>(S, P, B, lds_bytes, grid, stream);
+	if (sun) return alpha ? launch_pass_variant<MODE, true, true, false>(S, P, B, lds_bytes, grid, stream)
+	                      : launch_pass_variant<MODE, true, false, false>(S, P, B, lds_bytes, grid, stream);
+	return alpha ? launch_pass_variant<MODE, false, true, false>(S, P, B, lds_bytes, grid, stream)
+	             : launch_pass_variant<MODE, false, false, false>(S, P, B, lds_bytes, grid, stream);
+}
+hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, int mode, size_t lds_bytes, int grid,
+                              hipStream_t stream) {
+	if (mode == MODE_LDS) return launch_pass_mode<MODE_LDS>(S, P, B, lds_bytes, grid, stream);
+	if (mode == MODE_HYBRID) return launch_pass_mode<MODE_HYBRID>(S, P, B, lds_bytes, grid, stream);
+	return launch_pass_mode<MODE_GLOBAL>(S, P, B, lds_bytes, grid, stream);
 }
 hipError_t launch_resolve(const float4* sample_rad, float4* accum, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream) {
 	hipLaunchKernelGGL(k_resolve, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, sample_rad, accum, n_pixels, pass_spp);
 	return hipGetLastError();
 }
-hipError_t launch_intersect(const DevScene& S, const IntersectArgs& A, bool lds, size_t lds_bytes, int grid, hipStream_t stream) {
-	if (lds) {
-		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_intersect_batch<true>), lds_bytes);
+template <int MODE>
+static hipError_t launch_intersect_mode(const DevScene& S, const IntersectArgs& A, size_t lds_bytes, int grid, hipStream_t stream) {
+	if (MODE != MODE_GLOBAL) {
+		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_intersect_batch<MODE>), lds_bytes);
 		if (e != hipSuccess) return e;
-		hipLaunchKernelGGL(k_intersect_batch<true>, dim3(grid), dim3(kBlock), lds_bytes, stream, S, A, S.models, S.surfaces, S.spaces, S.model_space);
-	} else {
-		hipLaunchKernelGGL(k_intersect_batch<false>, dim3(grid), dim3(kBlock), 0, stream, S, A, S.models, S.surfaces, S.spaces, S.model_space);
 	}
+	hipLaunchKernelGGL(k_intersect_batch<MODE>, dim3(grid), dim3(kBlock), MODE != MODE_GLOBAL ? lds_bytes : 0, stream, S, A, S.models, S.surfaces, S.spaces, S.model_space);
 	return hipGetLastError();
+}
+hipError_t launch_intersect(const DevScene& S, const IntersectArgs& A, int mode, size_t lds_bytes, int grid, hipStream_t stream) {
+	if (mode == MODE_LDS) return launch_intersect_mode<MODE_LDS>(S, A, lds_bytes, grid, stream);
+	if (mode == MODE_HYBRID) return launch_intersect_mode<MODE_HYBRID>(S, A, lds_bytes, grid, stream);
+	return launch_intersect_mode<MODE_GLOBAL>(S, A, lds_bytes, grid, stream);
 }
 hipError_t launch_tonemap(const float4* accum, uint32_t n_pixels, float spp, uchar4* out, hipStream_t stream) {
 	hipLaunchKernelGGL(k_tonemap, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, accum, n_pixels, spp, out);

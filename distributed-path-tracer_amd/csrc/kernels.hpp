@@ -20,14 +20,25 @@ constexpr uint32_t kQueueFloat4PerWave = 22u * kChunk;  // 2 x 4 ray arrays + hi
 constexpr uint32_t kSpillWords = 24u * 64u;  // uint2 per wave: kSpillStack levels x 64 lanes
 
 // Device view of a FlatScene (all pointers are device pointers).
+// Where a scene's KD nodes and triangle records live while a kernel runs (kernel template parameter MODE):
+// everything in global memory (L2/HBM) | everything staged in LDS | hybrid: the surfaces that fit one CU's LDS
+// (SurfaceRec::lds_root valid) staged, the large ones in global memory.
+enum : int { MODE_GLOBAL = 0, MODE_LDS = 1, MODE_HYBRID = 2 };
+
 struct DevScene {
 	const ModelRec* models;
 	const SurfaceRec* surfaces;
 	const MaterialRec* materials;
-	const uint2* nodes;
-	const uint32_t* refs;
+	const uint2* nodes;      // KD nodes of all surfaces (global-memory traversal)
+	const uint32_t* refs;    // unused by the kernels since the global path reads leaf-ordered records; kept for ptx_scene_get_array parity
 	const float4* tris;   // 3 per triangle: corners + vertex ids (TriRec)
-	const float4* tri_isect; // TriIsect records: one per triangle (LDS-resident scenes) or one per leaf reference in leaf order, id in word 10 (others)
+	const float4* tri_isect; // global-memory traversal: one TriIsect per leaf reference, in leaf order, triangle id in word 10
+	// resident copy (staged into LDS by MODE_LDS / MODE_HYBRID kernels): nodes, refs and one TriIsect per triangle of the
+	// surfaces that fit, indices rewritten to be local to these arrays (SurfaceRec::lds_root)
+	const uint2* res_nodes;
+	const uint32_t* res_refs;
+	const float4* res_tris;
+	uint32_t n_res_nodes, n_res_refs, n_res_tris;
 	const float4* vattr;  // 2 per vertex
 	const ShadeRec* shade; // 1 per surface
 	const SpaceRec* spaces; // distinct world->local transforms
@@ -76,10 +87,10 @@ struct IntersectArgs {
 	uint2* spill;                                // [grid * waves per block][kSpillWords]
 };
 
-hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, bool lds, size_t lds_bytes, int grid,
+hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, int mode, size_t lds_bytes, int grid,
                               hipStream_t stream);
 hipError_t launch_resolve(const float4* sample_rad, float4* accum, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream);
-hipError_t launch_intersect(const DevScene& S, const IntersectArgs& A, bool lds, size_t lds_bytes, int grid, hipStream_t stream);
+hipError_t launch_intersect(const DevScene& S, const IntersectArgs& A, int mode, size_t lds_bytes, int grid, hipStream_t stream);
 hipError_t launch_tonemap(const float4* accum, uint32_t n_pixels, float spp, uchar4* out, hipStream_t stream);
 
 }  // namespace ptx

@@ -66,14 +66,26 @@ struct ptx_scene {
 	ptx_ctx* ctx = nullptr;
 	FlatScene host;
 	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr, d_isect, d_shade, d_tex, d_texels, d_lut, d_spaces, d_model_space;
+	DevBuf d_res_nodes, d_res_refs, d_res_tris;
 	DevScene dev{};
-	bool lds = false;
-	size_t lds_bytes = 0;
+	int mode = MODE_GLOBAL;   // where the traversal arrays live: MODE_GLOBAL / MODE_LDS / MODE_HYBRID (kernels.hip)
+	size_t lds_bytes = 0;     // dynamic LDS of the kernels (resident arrays + shade records)
 };
 
 namespace {
 
 size_t pad16(size_t b) { return (b + 15) & ~(size_t)15; }
+
+// Residency plan -> kernel family. PTX_FORCE_GLOBAL / PTX_NO_HYBRID: measurement switches.
+void decide_mode(ptx_scene* sc) {
+	FlatScene& h = sc->host;
+	plan_residency(h, kLdsBudget);
+	if (getenv("PTX_FORCE_GLOBAL") || h.n_resident == 0) sc->mode = MODE_GLOBAL;
+	else if (h.n_resident == h.surfaces.size()) sc->mode = MODE_LDS;
+	else sc->mode = getenv("PTX_NO_HYBRID") ? MODE_GLOBAL : MODE_HYBRID;
+	if (sc->mode == MODE_GLOBAL) for (auto& sr : h.surfaces) sr.lds_root = 0xFFFFFFFFu;
+	sc->lds_bytes = sc->mode == MODE_GLOBAL ? 0 : h.res_bytes;
+}
 
 int upload_scene(ptx_scene* sc) {
 	ptx_ctx* c = sc->ctx;
@@ -87,25 +99,24 @@ int upload_scene(ptx_scene* sc) {
 		return bytes ? hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess;
 	};
 	HIP_TRY(up(sc->d_models, h.models.data(), h.models.size() * sizeof(ModelRec), h.models.size() * sizeof(ModelRec)));
-	HIP_TRY(up(sc->d_surfaces, h.surfaces.data(), h.surfaces.size() * sizeof(SurfaceRec), h.surfaces.size() * sizeof(SurfaceRec)));
 	HIP_TRY(up(sc->d_materials, h.materials.data(), h.materials.size() * sizeof(MaterialRec), h.materials.size() * sizeof(MaterialRec)));
 	HIP_TRY(up(sc->d_nodes, h.kd_nodes.data(), h.kd_nodes.size() * 8, pad16(h.kd_nodes.size() * 8) + 16));   // + 16: the child-pair fetch of the last branch may read one node past the end
 	HIP_TRY(up(sc->d_refs, h.kd_refs.data(), h.kd_refs.size() * 4, pad16(h.kd_refs.size() * 4)));
 	HIP_TRY(up(sc->d_tris, h.tris.data(), h.tris.size() * 48, h.tris.size() * 48));
-	sc->lds_bytes = h.tris.size() * 48 + h.shade.size() * sizeof(ShadeRec) + pad16(h.kd_nodes.size() * 8) + pad16(h.kd_refs.size() * 4);
-	sc->lds = sc->lds_bytes <= kLdsBudget;
-	if (sc->lds) {
-		HIP_TRY(up(sc->d_isect, h.tri_isect.data(), h.tri_isect.size() * 48, h.tri_isect.size() * 48));
-	} else {
-		// geometry stays in L2/HBM: one record per leaf reference, in leaf order, so that a leaf's triangles are one
+	decide_mode(sc);   // sets SurfaceRec::lds_root: before the surface table goes up
+	HIP_TRY(up(sc->d_surfaces, h.surfaces.data(), h.surfaces.size() * sizeof(SurfaceRec), h.surfaces.size() * sizeof(SurfaceRec)));
+	if (sc->mode != MODE_LDS) {
+		// surfaces that stay in L2/HBM: one record per leaf reference, in leaf order, so that a leaf's triangles are one
 		// contiguous run and the reference -> record indirection is gone (Geom::leaf_ordered)
 		std::vector<TriIsect> leaf(h.kd_refs.size());
-		for (size_t r = 0; r < leaf.size(); r++) {
-			leaf[r] = h.tri_isect[h.kd_refs[r]];
-			memcpy(&leaf[r].p0, &h.kd_refs[r], 4);
-		}
+		for (size_t r = 0; r < leaf.size(); r++) leaf[r] = h.tri_isect[h.kd_refs[r]];
 		HIP_TRY(up(sc->d_isect, leaf.data(), leaf.size() * 48, leaf.size() * 48));
 		HIP_TRY(hipStreamSynchronize(c->stream));   // `leaf` is about to go out of scope
+	}
+	if (sc->mode != MODE_GLOBAL) {
+		HIP_TRY(up(sc->d_res_nodes, h.res_nodes.data(), h.res_nodes.size() * 8, pad16(h.res_nodes.size() * 8)));
+		HIP_TRY(up(sc->d_res_refs, h.res_refs.data(), h.res_refs.size() * 4, pad16(h.res_refs.size() * 4)));
+		HIP_TRY(up(sc->d_res_tris, h.res_tris.data(), h.res_tris.size() * 48, h.res_tris.size() * 48));
 	}
 	HIP_TRY(up(sc->d_vattr, h.vattr.data(), h.vattr.size() * 32, h.vattr.size() * 32));
 	HIP_TRY(up(sc->d_shade, h.shade.data(), h.shade.size() * sizeof(ShadeRec), h.shade.size() * sizeof(ShadeRec)));
@@ -128,6 +139,12 @@ int upload_scene(ptx_scene* sc) {
 	d.tris = (const float4*)sc->d_tris.p;
 	d.vattr = (const float4*)sc->d_vattr.p;
 	d.tri_isect = (const float4*)sc->d_isect.p;
+	d.res_nodes = (const uint2*)sc->d_res_nodes.p;
+	d.res_refs = (const uint32_t*)sc->d_res_refs.p;
+	d.res_tris = (const float4*)sc->d_res_tris.p;
+	d.n_res_nodes = (uint32_t)h.res_nodes.size();
+	d.n_res_refs = (uint32_t)h.res_refs.size();
+	d.n_res_tris = (uint32_t)h.res_tris.size();
 	d.shade = (const ShadeRec*)sc->d_shade.p;
 	d.spaces = (const SpaceRec*)sc->d_spaces.p;
 	d.tex = (const TexRec*)sc->d_tex.p;
@@ -154,8 +171,7 @@ int finish_scene(ptx_ctx* ctx, ptx_scene* sc, ptx_scene** out) {
 		int rc = upload_scene(sc);
 		if (rc != PTX_OK) { delete sc; return rc; }
 	} else {
-		sc->lds_bytes = sc->host.tris.size() * 48 + sc->host.shade.size() * sizeof(ShadeRec) + pad16(sc->host.kd_nodes.size() * 8) + pad16(sc->host.kd_refs.size() * 4);
-		sc->lds = sc->lds_bytes <= kLdsBudget;
+		decide_mode(sc);
 	}
 	*out = sc;
 	return PTX_OK;
@@ -334,8 +350,8 @@ int ptx_scene_get_info(const ptx_scene* sc, ptx_scene_info* info) {
 	info->n_kd_refs = (uint32_t)h.kd_refs.size();
 	info->kd_max_depth = h.kd_max_depth;
 	info->has_sun = h.sun.present;
-	info->geometry_bytes = (uint32_t)sc->lds_bytes;
-	info->lds_resident = sc->lds ? 1u : 0u;
+	info->geometry_bytes = (uint32_t)sc->host.geometry_bytes();
+	info->lds_resident = (uint32_t)sc->mode;
 	info->n_textures = (uint32_t)h.textures.size();
 	return PTX_OK;
 }
@@ -450,7 +466,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 		P.integrator = cfg->integrator;
 		HIP_TRY(hipMemsetAsync(chunk_counter, 0, 4, c->stream));
 		if (stats) HIP_TRY(hipEventRecord(c->events[2 * p], c->stream));
-		HIP_TRY(launch_render_pass(sc->dev, P, B, sc->lds, sc->lds_bytes, grid, c->stream));
+		HIP_TRY(launch_render_pass(sc->dev, P, B, sc->mode, sc->lds_bytes, grid, c->stream));
 		if (stats) HIP_TRY(hipEventRecord(c->events[2 * p + 1], c->stream));
 		HIP_TRY(launch_resolve(B.sample_rad, d_accum, P.n_pixels, P.pass_spp, c->stream));
 	}
@@ -522,7 +538,7 @@ int ptx_intersect_batch(ptx_scene* sc, const ptx_rays* r, size_t n, const ptx_hi
 	const int grid = (int)std::min<size_t>((size_t)c->n_cu, (n + kBlock - 1) / kBlock);
 	HIP_TRY(c->spill.ensure((size_t)c->n_cu * (kBlock / 64) * (size_t)kSpillWords * sizeof(uint2)));
 	A.spill = (uint2*)c->spill.p;
-	HIP_TRY(launch_intersect(sc->dev, A, sc->lds, sc->lds_bytes, grid, c->stream));
+	HIP_TRY(launch_intersect(sc->dev, A, sc->mode, sc->lds_bytes, grid, c->stream));
 	if (!dev) {
 		void* dst[14] = {hh->distance, hh->surface, hh->triangle, hh->b0, hh->b1, hh->b2, hh->px, hh->py, hh->pz, hh->nx, hh->ny, hh->nz, hh->u, hh->v};
 		const void* srcs[14] = {A.distance, A.surface, A.triangle, A.b0, A.b1, A.b2, A.px, A.py, A.pz, A.nx, A.ny, A.nz, A.u, A.v};

@@ -188,7 +188,10 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 			s.tris.push_back({a[0], a[1], a[2], (uint32_t)(v0 + ix[0]), b[0], b[1], b[2], (uint32_t)(v0 + ix[1]),
 			                  c[0], c[1], c[2], (uint32_t)(v0 + ix[2])});
 			const float e1[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]}, e2[3] = {a[0] - c[0], a[1] - c[1], a[2] - c[2]};
-			s.tri_isect.push_back({e2[1], e1[2], e2[2], e1[1], e1[0], e2[0], a[1], a[2], a[0], e1[1] * e2[2] - e2[1] * e1[2], 0.f, 0.f});
+			TriIsect rec{e2[1], e1[2], e2[2], e1[1], e1[0], e2[0], a[1], a[2], a[0], e1[1] * e2[2] - e2[1] * e1[2], 0.f, 0.f};
+			const uint32_t gid = (uint32_t)(t0 + t);   // every record carries its global triangle id (what a hit reports)
+			memcpy(&rec.p0, &gid, 4);
+			s.tri_isect.push_back(rec);
 		}
 		MeshBuilder mbuild{pa, pb, pc, {}, 0};
 		std::vector<uint32_t> all(nt);
@@ -311,6 +314,45 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 		s.sun.angular_radius = sun[12];
 		s.sun.present = 1;
 	}
+}
+
+void plan_residency(FlatScene& s, size_t lds_budget) {
+	const size_t n_surf = s.surfaces.size();
+	s.res_nodes.clear(); s.res_refs.clear(); s.res_tris.clear();
+	s.n_resident = 0;
+	for (auto& sr : s.surfaces) sr.lds_root = 0xFFFFFFFFu;
+	const size_t shade_bytes = s.shade.size() * sizeof(ShadeRec);
+	auto bytes_of = [&](size_t si) {
+		const int32_t* rg = &s.surf_range[8 * si];
+		return (size_t)rg[5] * 8 + (size_t)rg[7] * 4 + (size_t)rg[3] * 48;
+	};
+	std::vector<size_t> order(n_surf);
+	for (size_t i = 0; i < n_surf; i++) order[i] = i;
+	std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return bytes_of(a) < bytes_of(b); });
+	std::vector<char> take(n_surf, 0);
+	size_t used = shade_bytes + 48;   // 3 x 16 bytes: each region is padded to a multiple of 16
+	for (size_t si : order) {
+		if (used + bytes_of(si) > lds_budget) break;
+		used += bytes_of(si);
+		take[si] = 1;
+	}
+	for (size_t si = 0; si < n_surf; si++) {   // original surface order: with everything resident the copy is the identity
+		if (!take[si]) continue;
+		const int32_t* rg = &s.surf_range[8 * si];
+		const uint32_t t0 = (uint32_t)rg[2], nt = (uint32_t)rg[3], node0 = (uint32_t)rg[4], nn = (uint32_t)rg[5], ref0 = (uint32_t)rg[6], nr = (uint32_t)rg[7];
+		const uint32_t nb = (uint32_t)s.res_nodes.size(), rb = (uint32_t)s.res_refs.size(), tb = (uint32_t)s.res_tris.size();
+		for (uint32_t k = 0; k < nn; k++) {
+			KdNode nd = s.kd_nodes[node0 + k];
+			if ((nd.w1 & 3u) == KD_LEAF) nd.w0 = nd.w0 - ref0 + rb;                         // first ref
+			else nd.w1 = (nd.w1 & 15u) | ((((nd.w1 >> 4) - node0) + nb) << 4);              // first child
+			s.res_nodes.push_back(nd);
+		}
+		for (uint32_t k = 0; k < nr; k++) s.res_refs.push_back(s.kd_refs[ref0 + k] - t0 + tb);
+		for (uint32_t k = 0; k < nt; k++) s.res_tris.push_back(s.tri_isect[t0 + k]);
+		s.surfaces[si].lds_root = (s.surfaces[si].kd_root - node0) + nb;
+		s.n_resident++;
+	}
+	s.res_bytes = s.res_tris.size() * 48 + shade_bytes + ((s.res_nodes.size() * 8 + 15) & ~(size_t)15) + ((s.res_refs.size() * 4 + 15) & ~(size_t)15);
 }
 
 }  // namespace ptx

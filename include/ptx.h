@@ -112,7 +112,8 @@ typedef struct ptx_scene_info {
 	uint32_t kd_max_depth;
 	uint32_t has_sun;
 	uint32_t geometry_bytes;  /* nodes + refs + triangle records: what the kernels stage through LDS */
-	uint32_t lds_resident;    /* 1 when geometry_bytes fits one CU's LDS and the LDS kernels are used */
+	uint32_t lds_resident;    /* where the kernels read KD nodes / triangle records from: 0 = L2/HBM, 1 = all of it staged in
+	                           * each CU's LDS, 2 = hybrid (the surfaces that fit in LDS, the large ones in L2/HBM) */
 	uint32_t n_textures;
 } ptx_scene_info;
 int ptx_scene_get_info(const ptx_scene* scene, ptx_scene_info* info);

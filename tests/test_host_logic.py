@@ -215,7 +215,7 @@ def test_jack_product_loader_matches_reference(ptx, gold_jack, jack_arrays):
         assert rng[k, 5] == g["surf_range"][k, 5] and rng[k, 7] == g["surf_range"][k, 7]
         np.testing.assert_array_equal(sha_u8(kd_stream_packed(nodes, refs, rng[k, 4], int(rng[k, 2]))), g["sha_kd"][k])
     info = s.info()
-    assert info["n_triangles"] == 58740 and info["has_sun"] == 1 and info["lds_resident"] == 0 and info["n_textures"] == 17
+    assert info["n_triangles"] == 58740 and info["has_sun"] == 1 and info["lds_resident"] == 2 and info["n_textures"] == 17
     # texture slots and decoded texels against the oracle's loader (PIL decode): same slots, same sRGB flags, same bytes
     np.testing.assert_array_equal(s.array(ptx.ARR_SURF_TEX), jack_arrays.surf_tex)
     np.testing.assert_array_equal((s.array(ptx.ARR_SURF_TEX) >= 0).astype(np.uint8), g["material_tex"])

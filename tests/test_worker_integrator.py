@@ -156,7 +156,7 @@ def test_gpu_worker_plaza_matches_oracle(ptx, ctx, ora, sun, alpha, level):
     ref = _samples(o, ora, W, H, spp, b, 1)
     got = _gpu_samples(s, W, H, spp, b)
     assert _agree(got, ref) > 0.995
-    assert s.info()["lds_resident"] == int(level == 2)
+    assert s.info()["lds_resident"] == (1 if level == 2 else 2)
 
 
 @pytest.mark.gpu
