@@ -301,6 +301,37 @@ def test_plaza_sun_and_alpha_variants(ptx, ctx, ora, sun, alpha, level):
     assert info["has_sun"] == int(sun) and info["lds_resident"] == (1 if level == 2 else 2)   # level 3: ground + small sphere in LDS, the large sphere in L2/HBM
 
 
+@pytest.mark.parametrize("switch,mode", [("PTX_FORCE_GLOBAL", 0), ("PTX_NO_HYBRID", 0), ("", 2)])
+def test_all_three_residency_modes_agree(ptx, ctx, ora, monkeypatch, switch, mode):
+    """The same scene through the global-memory kernels (nothing staged) and the hybrid ones: bitwise the same samples — the copies
+    of a surface differ in layout (leaf-ordered records, rebased indices), never in arithmetic."""
+    from conftest import product_from_dict
+    d = _proc().plaza_scene(level=3, sun=True, alpha=True)
+    ref_scene = product_from_dict(ptx, ctx, d)
+    ref, _ = ref_scene.render(96, 54, 3, 6)
+    if switch:
+        monkeypatch.setenv(switch, "1")
+    s = product_from_dict(ptx, ctx, d)
+    assert s.info()["lds_resident"] == mode
+    got, _ = s.render(96, 54, 3, 6)
+    np.testing.assert_array_equal(got, ref)
+    got_w, _ = s.render(96, 54, 2, 6, integrator=1)
+    ref_w, _ = ref_scene.render(96, 54, 2, 6, integrator=1)
+    np.testing.assert_array_equal(got_w, ref_w)
+
+
+def test_cornell_on_global_memory_kernels(ptx, ctx, scene, monkeypatch):
+    """MODE_LDS vs MODE_GLOBAL on the headline scene: bitwise equal frames and hit records."""
+    from conftest import CORNELL
+    monkeypatch.setenv("PTX_FORCE_GLOBAL", "1")
+    g = ptx.Scene.load_gltf(ctx, CORNELL)
+    assert g.info()["lds_resident"] == 0 and scene.info()["lds_resident"] == 1
+    a, sa = scene.render(128, 72, 4, 8)
+    b, sb = g.render(128, 72, 4, 8)
+    np.testing.assert_array_equal(a, b)
+    assert sa["rays"] == sb["rays"]
+
+
 def test_config3_class_mesh_hybrid_residency(ptx, ctx, ora, cornell_arrays):
     """BASELINE config 3 class: ~80k-triangle mesh in the Cornell room: the mesh (9 MB) is traversed from L2/HBM, the room, boxes
     and light from LDS (hybrid kernels)."""
