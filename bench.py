@@ -31,15 +31,18 @@ B_RAY_CORNELL = 188 + 8 * 3.44 + 40 * 11.82 + 192
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
 
 
-def measured_traffic():
+def measured_traffic(rays_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile (FETCH_SIZE / WRITE_SIZE are collected
-    in separate rocprofv3 --pmc passes — tools/pmc_passes.sh — and cannot be read live here). None if no profile."""
+    in separate rocprofv3 --pmc passes — tools/pmc_passes.sh — and cannot be read live here): the measured bytes per ray
+    times the rays of this run's launches (a launch covers more samples than the profiled one; bytes per ray do not
+    depend on that). None if no profile."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")))
     if not files:
         return None
     with open(files[-1]) as fh:
-        return json.load(fh).get("traffic_bytes_per_launch")
+        per_ray = json.load(fh).get("traffic_bytes_per_ray")
+    return None if per_ray is None else round(per_ray * rays_per_launch)
 
 
 def measured_valu():
@@ -166,7 +169,7 @@ def main():
             "mrays_per_s": round(total_rays / dt / 1e6, 2),
             "rays_per_sample": round(total_rays / samples, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(rays_per_launch),
                          "algorithmic_bytes_per_launch": round(rays_per_launch * B_RAY_CORNELL),
                          "kernel": "k_render_pass<LDS>", "avg_launch_ms": round(kernel_ms, 4), "launches": launches,
                          "rays_per_launch": round(rays_per_launch), "bytes_per_ray": round(B_RAY_CORNELL, 2),

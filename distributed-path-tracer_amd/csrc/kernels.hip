@@ -755,12 +755,27 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 #endif
 
 	for (;;) {
-		uint32_t chunk = 0;
-		if (lane == 0) chunk = atomicAdd(B.chunk_counter, 1u);
-		chunk = __builtin_amdgcn_readfirstlane(chunk);
-		const uint64_t first = (uint64_t)chunk * kChunk;
+		// Guided self-scheduling: full chunks while plenty of paths are left, then chunks that shrink with what remains (a
+		// multiple of 64, at least 128), so that the waves of the launch run dry together instead of one chunk-time apart.
+		uint32_t first_lo = 0, first_hi = 0, take = 0;
+		if (lane == 0) {
+			const unsigned long long seen = __hip_atomic_load(B.chunk_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const unsigned long long left = seen < P.n_paths ? P.n_paths - seen : 0ull;
+			const unsigned long long n_waves = (unsigned long long)gridDim.x * (kBlock / 64);
+			// shrinking starts in the last round only (short chunks defer less efficiently), and only in launches of few
+			// rounds: over 16 rounds the uneven end is < 3 % of the launch and full chunks measured 1.5 % faster
+			unsigned long long want = P.n_paths >= 16ull * n_waves * kChunk ? (unsigned long long)kChunk : left / n_waves;
+			want = (want + 63ull) & ~63ull;
+			take = (uint32_t)(want < 128ull ? 128ull : (want > (unsigned long long)kChunk ? (unsigned long long)kChunk : want));
+			const unsigned long long f = atomicAdd(B.chunk_counter, (unsigned long long)take);
+			first_lo = (uint32_t)f; first_hi = (uint32_t)(f >> 32);
+		}
+		first_lo = __builtin_amdgcn_readfirstlane(first_lo);
+		first_hi = __builtin_amdgcn_readfirstlane(first_hi);
+		take = __builtin_amdgcn_readfirstlane(take);
+		const uint64_t first = ((uint64_t)first_hi << 32) | first_lo;
 		if (first >= P.n_paths) break;
-		uint32_t n_in = (uint32_t)((P.n_paths - first) < (uint64_t)kChunk ? (P.n_paths - first) : kChunk);
+		uint32_t n_in = (uint32_t)((P.n_paths - first) < (uint64_t)take ? (P.n_paths - first) : take);
 		if (P.bounces == 0)   // trace(0, ..) is black with alpha 1 (renderer.cpp:438-439): no vertex ever stores the sample
 			for (uint32_t i = lane; i < n_in; i += 64) B.sample_rad[(uint32_t)first + i] = make_float4(0.f, 0.f, 0.f, 1.0f);
 

@@ -74,7 +74,7 @@ struct PassBuffers {
 	float4* queues;                   // [n_wave_slots][kQueueFloat4PerWave]
 	float4* sample_rad;               // [pass_spp][n_pixels]
 	uint2* spill;                     // [n_wave_slots][kSpillWords]: traversal-stack overflow, lane-interleaved
-	uint32_t* chunk_counter;          // zeroed before each pass
+	unsigned long long* chunk_counter; // paths handed out so far; zeroed before each pass
 	unsigned long long* ray_counter;  // accumulates
 };
 
