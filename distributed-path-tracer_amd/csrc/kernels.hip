@@ -1,15 +1,17 @@
 // HIP kernels for gfx950 (MI355X / CDNA4): the ray-intersection + Monte-Carlo shading hot path.
 //
 // Design: one ray per lane, 64-lane waves. A launch is a grid of persistent
-// workgroups (one per CU) that first stage the scene geometry — 8-byte KD nodes, 4-byte leaf
-// references, 48-byte triangle records — into the CU's LDS (it is the only data touched in the
-// traversal inner loops), then each WAVE pulls chunks of camera paths from a global counter and runs
-// them through all bounces by itself: the rays of a chunk live in a wave-private SoA-of-float4 stream
-// in global memory (four coalesced 1-KiB loads per 64 rays), every bounce reads the stream, traces,
-// shades, and writes the survivors back compacted with a wave ballot + lane prefix count, so waves
-// stay full while paths die. No workgroup barrier, no inter-workgroup traffic, no atomics besides one
-// counter fetch per chunk; per-sample radiance leaves through plain stores and a second tiny kernel
-// adds the samples of each pixel in a fixed order (bitwise reproducible, no float atomics).
+// workgroups (one per CU) that first stage the traversal data that fits — 8-byte KD nodes, 4-byte leaf
+// references, 48-byte triangle records of the whole scene, or of its small surfaces while large meshes
+// stay in L2/HBM — into the CU's LDS, then each WAVE pulls chunks of camera paths from a global counter
+// and runs them to the end by itself: the paths of a chunk live in a wave-private SoA-of-float4 stream in
+// global memory (coalesced 1-KiB loads per 64 rays); every step sweeps the stream three times — EXTEND
+// (closest hits; rarely entered models set aside and traversed afterwards with full waves), SHADE
+// (BSDF, next ray, shadow requests; survivors written back compacted with a wave ballot + lane prefix
+// count, so waves stay full while paths die) and SHADOW (any-hit sweep over the requests). No workgroup
+// barrier after staging, no inter-workgroup traffic, no atomics besides one counter fetch per chunk;
+// per-sample radiance leaves through plain stores and a second tiny kernel adds the samples of each
+// pixel in a fixed order (bitwise reproducible, no float atomics).
 //
 // Numerics: IEEE binary32 in the reference's operation order, no FMA contraction (-ffp-contract=off),
 // correctly rounded divide / sqrt, the reference's double-precision islands kept in double. Each device
@@ -72,7 +74,7 @@ DEV V3 mulmv(const float* m, V3 v) {
 }
 
 // ------------------------------------------------------------------------------------ geometry access
-// The three traversal arrays, either in LDS (whole scene staged per workgroup) or in global memory.
+// The three traversal arrays of one copy of the geometry: the LDS-resident one or the global-memory one.
 struct Geom {
 	const uint2* nodes;
 	const uint32_t* refs;
@@ -731,9 +733,10 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 
 // ------------------------------------------------------------------------------------ integrator kernel
 // One launch = `P.n_paths` camera paths (P.pass_spp samples of every tile pixel), all bounces.
-// Per wave and chunk of kChunk paths, every bounce is two sweeps over the wave's private ray stream:
+// Per wave and chunk of up to kChunk paths, every step is up to three sweeps over the wave's private stream:
 //   EXTEND: (generate or) load ray -> closest hit -> 16-byte hit record        (traversal state only in registers)
-//   SHADE : load ray + hit + path state -> BSDF, radiance, next ray -> compacted write (path state only)
+//   SHADE : load ray + hit + path state -> BSDF, radiance, next ray, shadow request -> compacted writes (no traversal)
+//   SHADOW: load request -> any hit? -> add the sun contribution / resolve a pending shadow catcher   (SUN variants)
 template <int MODE, bool SUN, bool ALPHA, bool TEX, bool WORKER>
 __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParams P, PassBuffers B, const ModelRec* __restrict__ t_models, const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
 	DevScene S = S0;
