@@ -248,9 +248,14 @@ struct Loader {
 	}
 
 	Entity* process_node(size_t ni, Entity* parent) {  // renderer.cpp:101-174
+		// a node hierarchy with a cycle would recurse forever in the reference; here it is a parse error
+		int depth = 0;
+		for (const Entity* a = parent; a; a = a->parent) depth++;
+		if (depth > 512) fail(E_PARSE, "glTF: node hierarchy deeper than 512 levels (cycle?)");
 		const JVal& n = g.root.at("nodes").el(ni);
 		pool.emplace_back(new Entity);
 		Entity* e = pool.back().get();
+		e->parent = parent;
 		const JVal* light_ref = nullptr;
 		if (const JVal* ext = n.find("extensions"))
 			if (const JVal* kl = ext->find("KHR_lights_punctual")) light_ref = kl->find("light");

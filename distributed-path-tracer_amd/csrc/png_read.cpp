@@ -49,6 +49,7 @@ void read_png(const std::string& path, uint32_t& W, uint32_t& H, uint32_t& C, st
 		p += 12 + (size_t)len;
 	}
 	if (!have_hdr || !W || !H) bad(path, "missing IHDR");
+	if (W > 65536u || H > 65536u) bad(path, "image dimensions out of range");   // before any allocation sized by them
 	if (interlace) bad(path, "interlaced PNGs are not supported");
 	uint32_t src_ch;
 	switch (ctype) {

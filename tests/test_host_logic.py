@@ -319,3 +319,147 @@ def test_worker_event_and_primitive_filter(ptx, ora, tmp_path):
     with pytest.raises(ptx.PtxError) as e:
         ptx.Scene.load_event(None, str(bad), root)
     assert e.value.code == ptx.ERR_PARSE
+
+
+# ---------------------------------------------------------------------------- malformed inputs: an error code, never a crash
+def _expect_error_or_load(ptx, path):
+    try:
+        ptx.Scene.load_gltf(None, path)
+        return "loaded"
+    except ptx.PtxError as e:
+        assert e.code in (ptx.ERR_IO, ptx.ERR_PARSE, ptx.ERR_INVALID, ptx.ERR_NO_CAMERA, ptx.ERR_UNSUPPORTED), e
+        return "error"
+
+
+def test_malformed_gltf_is_an_error_not_a_crash(ptx, tmp_path):
+    """Out-of-range indices, missing / short buffers, wrong accessor types, a node cycle (the reference would recurse forever),
+    and the document truncated at 60 random places."""
+    import copy
+    import json
+    import random
+    import shutil
+    src = os.path.dirname(CORNELL)
+    base = json.load(open(CORNELL))
+    binname = base["buffers"][0]["uri"]
+    binb = open(os.path.join(src, binname), "rb").read()
+
+    def attempt(doc=None, raw=None, bin_bytes=None):
+        d = tmp_path / "case"
+        shutil.rmtree(d, ignore_errors=True)
+        d.mkdir()
+        if bin_bytes is None:
+            (d / binname).write_bytes(binb)
+        elif bin_bytes is not False:
+            (d / binname).write_bytes(bin_bytes)
+        (d / "s.gltf").write_text(raw if raw is not None else json.dumps(doc))
+        return _expect_error_or_load(ptx, str(d / "s.gltf"))
+
+    assert attempt(base) == "loaded"
+    assert attempt(base, bin_bytes=False) == "error"
+    assert attempt(base, bin_bytes=binb[:len(binb) // 2]) == "error"
+    muts = [lambda d: d["bufferViews"][0].__setitem__("byteOffset", 10 ** 9),
+            lambda d: d["accessors"][0].__setitem__("count", 10 ** 8),
+            lambda d: d["accessors"][0].__setitem__("bufferView", 999),
+            lambda d: d["accessors"][0].__setitem__("componentType", 1234),
+            lambda d: d["accessors"][0].__setitem__("type", "MAT4"),
+            lambda d: d["meshes"][0]["primitives"][0]["attributes"].pop("POSITION"),
+            lambda d: d["meshes"][0]["primitives"][0]["attributes"].__setitem__("POSITION", 9999),
+            lambda d: d["meshes"][0]["primitives"][0].__setitem__("indices", 9999),
+            lambda d: d["meshes"][0]["primitives"][0].__setitem__("material", 9999),
+            lambda d: d["nodes"][0].__setitem__("mesh", 9999),
+            lambda d: d["nodes"][0].__setitem__("children", [9999]),
+            lambda d: d["nodes"][0].__setitem__("children", [0]),          # cycle
+            lambda d: d["scenes"][0].__setitem__("nodes", [9999]),
+            lambda d: d.pop("accessors"),
+            lambda d: d.__setitem__("meshes", "x")]
+    for m in muts:
+        d = copy.deepcopy(base)
+        m(d)
+        assert attempt(d) == "error", m
+    ia = base["accessors"][base["meshes"][0]["primitives"][0]["indices"]]
+    bv = base["bufferViews"][ia["bufferView"]]
+    off = bv.get("byteOffset", 0) + ia.get("byteOffset", 0)
+    bb = bytearray(binb)
+    bb[off:off + 2] = (65535).to_bytes(2, "little")                          # an index beyond the vertex count
+    assert attempt(base, bin_bytes=bytes(bb)) == "error"
+    raw = json.dumps(base)
+    rnd = random.Random(1)
+    for _ in range(60):
+        assert attempt(raw=raw[:rnd.randrange(1, len(raw))]) == "error"
+
+
+def test_malformed_png_is_an_error_not_a_crash(ptx, tmp_path):
+    """Texture files that are truncated, bit-flipped, or lie about their size / type."""
+    import json
+    import random
+    import struct
+    import zlib
+    from PIL import Image
+    gl = {"asset": {"version": "2.0"}, "scenes": [{"nodes": [0, 1]}], "cameras": [{"name": "c", "type": "perspective", "perspective": {"yfov": 0.7}}],
+          "nodes": [{"camera": 0, "name": "c"}, {"mesh": 0, "name": "m"}], "buffers": [{"uri": "b.bin", "byteLength": 132}],
+          "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 24},
+                          {"buffer": 0, "byteOffset": 60, "byteLength": 36}, {"buffer": 0, "byteOffset": 96, "byteLength": 6}],
+          "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": 3, "type": "VEC2"},
+                        {"bufferView": 2, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 3, "componentType": 5123, "count": 3, "type": "SCALAR"}],
+          "images": [{"uri": "t.png"}], "textures": [{"source": 0}], "materials": [{"name": "m", "pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}],
+          "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1, "NORMAL": 2}, "indices": 3, "material": 0}]}]}
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    blob = pos.tobytes() + np.zeros((3, 2), np.float32).tobytes() + np.tile(np.float32([0, 0, 1]), 3).tobytes() + np.uint16([0, 1, 2]).tobytes() + b"\0" * 30
+    (tmp_path / "b.bin").write_bytes(blob[:132])
+    (tmp_path / "s.gltf").write_text(json.dumps(gl))
+    img = (np.random.default_rng(3).random((23, 31, 4)) * 255).astype(np.uint8)
+    Image.fromarray(img, "RGBA").save(tmp_path / "good.png")
+    good = (tmp_path / "good.png").read_bytes()
+
+    def attempt(data):
+        (tmp_path / "t.png").write_bytes(data)
+        return _expect_error_or_load(ptx, str(tmp_path / "s.gltf"))
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    def png(w, h, depth, ctype, interlace, idat):
+        return good[:8] + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace)) + chunk(b"IDAT", idat) + chunk(b"IEND", b"")
+
+    raw = b"".join(b"\0" + bytes(31 * 4) for _ in range(23))
+    assert attempt(good) == "loaded"
+    assert attempt(png(31, 23, 8, 6, 0, zlib.compress(raw))) == "loaded"
+    for bad in (b"", good[:8], png(2 ** 31 - 1, 2 ** 31 - 1, 8, 6, 0, zlib.compress(raw)), png(0, 0, 8, 6, 0, zlib.compress(raw)),
+                png(4096, 4096, 8, 6, 0, zlib.compress(raw)), png(31, 23, 8, 7, 0, zlib.compress(raw)), png(31, 23, 3, 6, 0, zlib.compress(raw)),
+                png(31, 23, 8, 6, 1, zlib.compress(raw)), png(31, 23, 8, 6, 0, zlib.compress(raw.replace(b"\0" + bytes(124), b"\x09" + bytes(124)))),
+                png(31, 23, 8, 6, 0, zlib.compress(raw[:100])), png(31, 23, 8, 6, 0, b"\x12\x34" * 50),
+                png(31, 23, 8, 3, 0, zlib.compress(b"".join(b"\0" + bytes([200] * 31) for _ in range(23)))),
+                good[:8] + struct.pack(">I", 0xFFFFFFF0) + b"IHDR" + good[16:]):
+        assert attempt(bad) == "error"
+    rnd = random.Random(2)
+    for _ in range(60):
+        assert attempt(good[:rnd.randrange(1, len(good))]) == "error"
+    for _ in range(120):                       # a flipped byte either fails a check or still decodes: both are fine, a crash is not
+        b = bytearray(good)
+        for _ in range(rnd.randrange(1, 4)):
+            b[rnd.randrange(8, len(b))] = rnd.randrange(256)
+        attempt(bytes(b))
+
+
+def test_malformed_worker_event_is_an_error(ptx, tmp_path):
+    import json
+    import random
+    work = {"Cube.003": [0, 1, 2]}
+    ev_path, root = _event(tmp_path, work, samples=2, bounces=2, X=8, Y=8)
+    raw = open(ev_path).read()
+    rnd = random.Random(3)
+    bad = tmp_path / "bad_event.json"
+    for _ in range(40):
+        bad.write_text(raw[:rnd.randrange(1, len(raw) - 1)])
+        with pytest.raises(ptx.PtxError) as e:
+            ptx.Scene.load_event(None, str(bad), root)
+        assert e.value.code in (ptx.ERR_PARSE, ptx.ERR_INVALID)
+    doc = json.loads(raw)
+    for key, val in (("samples", -1), ("bounces", 0), ("X", 0), ("Y", -5)):
+        d = json.loads(raw)
+        tgt = d["scene_info"] if key in d.get("scene_info", {}) else d
+        tgt[key] = val
+        bad.write_text(json.dumps(d))
+        with pytest.raises(ptx.PtxError):
+            ptx.Scene.load_event(None, str(bad), root)
+    assert doc
