@@ -149,6 +149,7 @@ def lib():
         L.ptx_render.argtypes = [C.c_void_p, C.POINTER(RenderCfg), C.c_void_p, C.POINTER(RenderStats)]
         L.ptx_intersect_batch.argtypes = [C.c_void_p, C.POINTER(Rays), C.c_size_t, C.POINTER(Hits)]
         L.ptx_tonemap_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.ptx_reduce_framebuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.ptx_encode_png.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.ptx_free.argtypes = [C.c_void_p]
         _lib = L
@@ -188,6 +189,13 @@ class Context:
 
     def synchronize(self):
         _check(lib().ptx_ctx_synchronize(self.h))
+
+    def reduce_framebuffer(self, nccl_comm, accum, root=0):
+        """ptx_reduce_framebuffer: in-place RCCL sum-reduce of a device-resident accumulation buffer onto `root`, on this
+        context's stream. `nccl_comm`: the raw ncclComm_t (an int / ctypes pointer) of a communicator the caller created."""
+        n = int(accum.numel()) if hasattr(accum, "numel") else int(accum.size)
+        comm = nccl_comm if isinstance(nccl_comm, C.c_void_p) else C.c_void_p(int(nccl_comm))
+        _check(lib().ptx_reduce_framebuffer(self.h, comm, _ptr(accum), n, root))
 
     def tonemap_encode(self, accum, W, H, spp, out=None):
         """accum: [H,W,4] float32 sums (numpy or torch-on-GPU). Returns/filles RGBA8 [H,W,4]."""

@@ -1,6 +1,7 @@
 // C ABI of libptx_hip.so (declared in include/ptx.h). Host glue only: contexts, scene upload,
 // pass scheduling, staging of host buffers. All arithmetic of the hot path lives in kernels.hip;
 // there is no CPU fallback — GPU entry points fail with PTX_ERR_NO_DEVICE when no HIP device exists.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <zlib.h>
 
@@ -546,6 +547,26 @@ int ptx_intersect_batch(ptx_scene* sc, const ptx_rays* r, size_t n, const ptx_hi
 			if (dst[k]) HIP_TRY(hipMemcpyAsync(dst[k], srcs[k], n * 4, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
+	return PTX_OK;
+}
+
+int ptx_reduce_framebuffer(ptx_ctx* c, void* nccl_comm, float* accum, size_t n_floats, int root) {
+	if (!c || !nccl_comm || !accum) return set_err(PTX_ERR_INVALID, "ptx_reduce_framebuffer: NULL argument");
+	if (!is_device_ptr(accum)) return set_err(PTX_ERR_INVALID, "ptx_reduce_framebuffer: accum must be device memory");
+	// ncclResult_t ncclReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) — rccl.h
+	using reduce_fn = int (*)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
+	static reduce_fn fn = [] {
+		void* sym = dlsym(RTLD_DEFAULT, "ncclReduce");            // the RCCL that created the communicator, if already loaded
+		if (!sym)
+			if (void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL)) sym = dlsym(h, "ncclReduce");
+		return reinterpret_cast<reduce_fn>(sym);
+	}();
+	if (!fn) return set_err(PTX_ERR_UNSUPPORTED, "ptx_reduce_framebuffer: no RCCL (ncclReduce) in this process and librccl.so cannot be loaded");
+	std::lock_guard<std::mutex> lk(c->mu);
+	HIP_TRY(hipSetDevice(c->device));
+	constexpr int kNcclFloat32 = 7, kNcclSum = 0;                 // rccl.h: ncclFloat32 = 7, ncclSum = 0
+	const int rc = fn(accum, accum, n_floats, kNcclFloat32, kNcclSum, root, nccl_comm, c->stream);
+	if (rc != 0) return set_err(PTX_ERR_HIP, "ncclReduce failed with ncclResult_t " + std::to_string(rc));
 	return PTX_OK;
 }
 

@@ -195,6 +195,17 @@ typedef struct ptx_hits {
 } ptx_hits;
 int ptx_intersect_batch(ptx_scene* scene, const ptx_rays* rays, size_t n, const ptx_hits* hits);
 
+/* ---- multi-GPU fan-in ------------------------------------------------------------------------------
+ * The one exchange step of the path: the sum of the per-rank accumulation buffers on rank `root`. Replaces the
+ * reference's planned (never implemented) SNS/SQS result fan-in (src/models/work_info.hpp:22-23,
+ * src/processors/worker/intersection_worker.cpp:69-147). `nccl_comm` is an RCCL communicator the host created
+ * (ncclCommInitRank: one rank per GPU); the library does not link RCCL, it resolves ncclReduce from the RCCL the
+ * process has already loaded (or from librccl.so) at the first call, and enqueues
+ * ncclReduce(accum, accum, n_floats, ncclFloat32, ncclSum, root, comm, ptx_ctx_stream(ctx)) — in place, device memory.
+ * Call ptx_ctx_synchronize (or chain work on that stream) before reading the result. PTX_ERR_UNSUPPORTED when no RCCL
+ * can be found, PTX_ERR_HIP when RCCL reports an error. */
+int ptx_reduce_framebuffer(ptx_ctx* ctx, void* nccl_comm, float* accum_rgba, size_t n_floats, int root);
+
 /* ---- image write --------------------------------------------------------------------------------
  * Replaces the tonemap + image::write loop of renderer.cpp:409-424 (core::tonemap_approx_aces,
  * LIB/core/utils.hpp:29-36; image::image::write, LIB/image/image.cpp:143-154): divides the sums by

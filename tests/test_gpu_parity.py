@@ -239,6 +239,40 @@ def test_tile_sharding_on_device_buffers(scene, ptx):
     assert rays > 0
 
 
+def test_reduce_framebuffer_through_rccl(scene, ctx, ptx):
+    """ptx_reduce_framebuffer with a communicator made the way a C++ host would (ncclGetUniqueId / ncclCommInitRank straight
+    from librccl). One rank is all a single-GPU box allows: the in-place sum over one rank must return the buffer unchanged,
+    through the library's dlsym'ed ncclReduce, on the context's stream."""
+    import ctypes
+    import os
+    import torch
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=ctypes.RTLD_GLOBAL)
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        W, H = 64, 36
+        acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+        scene.render(W, H, 3, 4, accum=acc)
+        before = acc.cpu().numpy().copy()
+        ctx.reduce_framebuffer(comm, acc, root=0)
+        ctx.synchronize()
+        np.testing.assert_array_equal(acc.cpu().numpy(), before)
+        with pytest.raises(ptx.PtxError) as e:
+            ctx.reduce_framebuffer(comm, np.zeros(4, np.float32))      # host memory is refused
+        assert e.value.code == ptx.ERR_INVALID
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
 def test_cpp_host_cli(cornell_oracle, ora, tmp_path):
     """The C++ mirror of core::renderer (host/ptx_renderer.hpp) driven by host/render_main.cpp: PNG vs the oracle."""
     import os
