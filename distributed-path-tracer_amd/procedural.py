@@ -127,3 +127,83 @@ def cornell_with_mesh(cornell: dict, level: int = 6, seed: int = 7):
     return dict(model_xform=np.asarray(cornell["model_xform"], np.float32), model_surf=np.asarray(cornell["model_surf"], np.int32),
                 surf_range=surf_range, vertices=verts.astype(np.float32), triangles=tris.astype(np.uint32),
                 materials=np.asarray(cornell["materials"], np.float32), camera=np.asarray(cornell["camera"], np.float32)[:13], sun=None)
+
+
+def _grid(n: int, origin, du, dv):
+    """n x n quads (2 n^2 triangles) spanning origin + s*du + t*dv, s,t in [0,1]; normal = normalize(du x dv)."""
+    origin, du, dv = (np.asarray(a, np.float64) for a in (origin, du, dv))
+    s, t = np.meshgrid(np.linspace(0, 1, n + 1), np.linspace(0, 1, n + 1), indexing="ij")
+    p = origin + s[..., None] * du + t[..., None] * dv
+    nrm = np.cross(du, dv)
+    nrm /= np.linalg.norm(nrm)
+    tan = du / np.linalg.norm(du)
+    v = np.zeros(((n + 1) ** 2, 11), np.float32)
+    v[:, 0:3] = p.reshape(-1, 3)
+    v[:, 3:5] = np.stack([s, t], -1).reshape(-1, 2)
+    v[:, 5:8] = nrm
+    v[:, 8:11] = tan
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    a = (i * (n + 1) + j).ravel()
+    b, c, d = a + (n + 1), a + (n + 1) + 1, a + 1
+    tri = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)]).astype(np.uint32)
+    return v, tri
+
+
+def _place(v, scale, offset):
+    """Scale + translate a vertex array in place of a node transform (one model, many surfaces); normals by the inverse-transpose."""
+    out = v.copy()
+    sc = np.asarray(scale, np.float32)
+    out[:, 0:3] = v[:, 0:3] * sc + np.asarray(offset, np.float32)
+    n = v[:, 5:8] / sc
+    out[:, 5:8] = n / np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-20)
+    t = v[:, 8:11] * sc
+    out[:, 8:11] = t / np.maximum(np.linalg.norm(t, axis=1, keepdims=True), 1e-20)
+    return out
+
+
+def atrium_scene(detail: int = 5, seed: int = 11):
+    """Sponza-class stand-in for BASELINE configs 4-5 (`sponza.bin` is missing from the reference): ONE model with 24 surfaces
+    (as Sponza's single mesh has 24 primitives) — a gridded floor and three walls, two rows of five tall columns, eight
+    ornaments, a lintel and a plinth — lit by one directional light through the open roof. detail = 5 gives 262 176 triangles
+    (Sponza's accessors total 262 267); every level down divides the sphere-derived part by four."""
+    parts = []
+    g = max(detail - 1, 0)
+    parts.append(_grid(4 << g, [-6, 0, -14], [0, 0, 28], [12, 0, 0]))                 # floor, normal +y
+    parts.append(_grid(2 << g, [-6, 0, -14], [0, 9, 0], [0, 0, 28]))                  # left wall, normal +x
+    parts.append(_grid(2 << g, [6, 0, 14], [0, 9, 0], [0, 0, -28]))                   # right wall, normal -x
+    parts.append(_grid(2 << g, [-6, 0, -14], [12, 0, 0], [0, 9, 0]))                  # back wall, normal +z
+    col_v, col_t = displaced_icosphere(detail, seed, 0.10)
+    for k in range(10):
+        x = -3.2 if k % 2 == 0 else 3.2
+        z = -11.0 + 5.0 * (k // 2)
+        parts.append((_place(col_v, (0.55, 3.6, 0.55), (x, 3.6, z)), col_t))
+    orn_v, orn_t = displaced_icosphere(max(detail - 1, 0), seed + 1, 0.25)
+    for k in range(8):
+        x = -1.6 + 3.2 * (k % 2)
+        z = -9.0 + 5.5 * (k // 2)
+        parts.append((_place(orn_v, (0.7, 0.7, 0.7), (x, 0.75 + 0.5 * (k % 3), z)), orn_t))
+    parts.append(_grid(1 << g, [-6, 8.2, -14], [12, 0, 0], [0, 0, 6]))                # lintel over the far end, normal -y
+    parts.append(_grid((7 << g) // 4 or 1, [-2, 0.02, 6], [0, 0, 4], [4, 0, 0]))      # plinth, normal +y
+    assert len(parts) == 24
+    verts = np.concatenate([p[0] for p in parts]).astype(np.float32)
+    tris = np.concatenate([p[1] for p in parts]).astype(np.uint32)
+    sr, v0, t0 = [], 0, 0
+    for v, t in parts:
+        sr.append([v0, len(v), t0, len(t)])
+        v0 += len(v); t0 += len(t)
+    rng = np.random.default_rng(seed)
+    mats = np.zeros((24, 11), np.float32)
+    mats[:, 0:3] = 0.35 + 0.55 * rng.random((24, 3))
+    mats[:, 3] = 1.0
+    mats[:, 4] = 0.25 + 0.7 * rng.random(24)
+    mats[4:14, 5] = (rng.random(10) < 0.3)            # a few metallic columns
+    mats[:, 9] = 1.45
+    d = np.array([0.25, 0.85, 0.35])                  # towards the sun
+    d /= np.linalg.norm(d)
+    x = np.cross([0, 1, 0], d); x /= np.linalg.norm(x)
+    y = np.cross(d, x)
+    sun13 = np.concatenate([x, y, d, [4.0, 3.7, 3.2], [0.004732]]).astype(np.float32)
+    cam = np.concatenate([_look_at([0.3, 2.2, 13.0], [0.0, 2.6, -6.0]), [np.float32(0.9)]]).astype(np.float32)
+    ident = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    return dict(model_xform=np.array([[0, 0, 0] + ident], np.float32), model_surf=np.array([[0, 24]], np.int32),
+                surf_range=np.array(sr, np.int32), vertices=verts, triangles=tris, materials=mats, camera=cam, sun=sun13)

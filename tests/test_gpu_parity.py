@@ -366,6 +366,23 @@ def test_cornell_on_global_memory_kernels(ptx, ctx, scene, monkeypatch):
     assert sa["rays"] == sb["rays"]
 
 
+@pytest.mark.parametrize("detail", [1, 3])
+def test_sponza_class_single_model_many_surfaces(ptx, ctx, ora, detail):
+    """BASELINE configs 4-5 class (procedural stand-in, `sponza.bin` is missing from the reference): one model with 24 surfaces
+    under a directional light; hit records bit-exact, per-sample radiance and the 8-bit image against the oracle."""
+    d = _proc().atrium_scene(detail)
+    assert len(d["surf_range"]) == 24 and d["model_surf"].tolist() == [[0, 24]]
+    s, o = _scene_parity(ptx, ctx, ora, d, 96, 54, 3, 6, n_rays=20_000)
+    W, H, spp, b = 192, 108, 8, 6
+    mean, ost = o.render(ora.make_cfg(W, H, spp, b), threads=0)
+    accum, gst = s.render(W, H, spp, b)
+    assert abs(gst["rays"] - int(ost[0])) <= 2e-4 * int(ost[0])
+    assert ora.psnr8(ctx.tonemap_encode(accum, W, H, spp), ora.tonemap_write(mean)) >= 40.0
+    accum_w, _ = s.render(W, H, spp, b, integrator=1)
+    mean_w, _ = o.render(ora.make_cfg(W, H, spp, b, integrator=1), threads=0)
+    assert ora.psnr8(ctx.tonemap_encode(accum_w, W, H, spp), ora.tonemap_write(mean_w)) >= 40.0
+
+
 def test_config3_class_mesh_hybrid_residency(ptx, ctx, ora, cornell_arrays):
     """BASELINE config 3 class: ~80k-triangle mesh in the Cornell room: the mesh (9 MB) is traversed from L2/HBM, the room, boxes
     and light from LDS (hybrid kernels)."""

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 ap = argparse.ArgumentParser(); ap.add_argument("--spp", type=int, default=32); ap.add_argument("--level7", action="store_true")
-ap.add_argument("--only", default="", help="comma list of: cornell, jack, plaza, mesh6, mesh7")
+ap.add_argument("--only", default="", help="comma list of: cornell, jack, plaza, atrium, mesh6, mesh7")
 ap.add_argument("--integrator", type=int, default=0)
 args = ap.parse_args()
 ptx = importlib.import_module("distributed-path-tracer_amd")
@@ -42,6 +42,12 @@ if want("plaza"):
     d = proc.plaza_scene(level=5, sun=True, alpha=True)
     sp = ptx.Scene.from_arrays(ctx, d["model_xform"], d["model_surf"], d["surf_range"], d["vertices"], d["triangles"], d["materials"], d["camera"], d["sun"])
     run("plaza: sun + shadow catcher + translucent sphere (25.6k tris)", sp, args.spp)
+if want("atrium"):
+    t0 = time.time()
+    d = proc.atrium_scene(5)
+    sa = ptx.Scene.from_arrays(ctx, d["model_xform"], d["model_surf"], d["surf_range"], d["vertices"], d["triangles"], d["materials"], d["camera"], d["sun"])
+    print("atrium scene build: %.1f s" % (time.time() - t0), flush=True)
+    run("atrium: one model, 24 surfaces, 262 176 triangles, sun (config 4/5 class)", sa, args.spp)
 if want("mesh6"):
     t0 = time.time()
     d = proc.cornell_with_mesh(c, level=6)
