@@ -60,6 +60,7 @@ struct SurfaceRec {
 	uint32_t kd_root;        // index of the root KD node in the full node array
 	uint32_t tri_base;       // global id of the mesh's triangle 0
 	uint32_t lds_root;       // index of the root in the LDS-resident node array, 0xFFFFFFFF when the surface is not resident
+	uint32_t model;          // the model this surface belongs to
 };
 
 // ---- material factors (core/material.hpp:11-17) and texture slots ----

@@ -175,11 +175,11 @@ DEV bool aabb_test_inv(const float* mn, const float* mx, V3 o, V3 inv, float& nr
 // Stack entries are (node, min_dist) only: the max_dist the reference stores with an entry is always the
 // min_dist of the entry beneath it (each push hands its old max_dist to the pushed subtree and continues
 // with max_dist = split_dist = the pushed min_dist), and the AABB exit distance for the bottom one.
+// (nr, fr) = the surface box's entry / exit distances (mesh.cpp:308-315): tested by the caller, which may decide with the
+// result whether the lane traverses now or is set aside for a full-wave sweep.
 template <int PB>
-DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, uint32_t root, V3 o, V3 d, V3 inv, MeshHit& out, const Spill& spill PROF_ARG) {
+DEV bool mesh_traverse(const Geom& g, uint32_t root, float nr, float fr, V3 o, V3 d, MeshHit& out, const Spill& spill PROF_ARG) {
 	PROF(PB);
-	float nr, fr;
-	if (!aabb_test_inv(sf.bmin, sf.bmax, o, inv, nr, fr)) return false;
 	const PRay pr = pack_ray(o, d);
 	int sp = 0;
 	uint32_t n0 = 0, n1 = 0, n2 = 0;  // register stack: entry 0 is the top
@@ -257,15 +257,22 @@ DEV bool mesh_traverse(const Geom& g, const SurfaceRec& sf, uint32_t root, V3 o,
 	}
 }
 
-// core::mesh::intersect on whichever copy of the surface's tree the scene's MODE prescribes
+// core::mesh::intersect on whichever copy of the surface's tree the scene's MODE prescribes; (nr, fr) from the box test
 template <int MODE, int PB>
-DEV bool mesh_traverse_m(const Geoms& G, const SurfaceRec& sf, V3 o, V3 d, V3 inv, MeshHit& out, const Spill& spill PROF_ARG) {
-	if constexpr (MODE == MODE_GLOBAL) return mesh_traverse<PB>(G.glb, sf, sf.kd_root, o, d, inv, out, spill PROF_PASS);
-	else if constexpr (MODE == MODE_LDS) return mesh_traverse<PB>(G.lds, sf, sf.lds_root, o, d, inv, out, spill PROF_PASS);
+DEV bool mesh_traverse_m(const Geoms& G, const SurfaceRec& sf, float nr, float fr, V3 o, V3 d, MeshHit& out, const Spill& spill PROF_ARG) {
+	if constexpr (MODE == MODE_GLOBAL) return mesh_traverse<PB>(G.glb, sf.kd_root, nr, fr, o, d, out, spill PROF_PASS);
+	else if constexpr (MODE == MODE_LDS) return mesh_traverse<PB>(G.lds, sf.lds_root, nr, fr, o, d, out, spill PROF_PASS);
 	else {
-		if (sf.lds_root != 0xFFFFFFFFu) return mesh_traverse<PB>(G.lds, sf, sf.lds_root, o, d, inv, out, spill PROF_PASS);
-		return mesh_traverse<PB>(G.glb, sf, sf.kd_root, o, d, inv, out, spill PROF_PASS);
+		if (sf.lds_root != 0xFFFFFFFFu) return mesh_traverse<PB>(G.lds, sf.lds_root, nr, fr, o, d, out, spill PROF_PASS);
+		return mesh_traverse<PB>(G.glb, sf.kd_root, nr, fr, o, d, out, spill PROF_PASS);
 	}
+}
+// ... including the box test (mesh.cpp:308-315)
+template <int MODE, int PB>
+DEV bool mesh_intersect_m(const Geoms& G, const SurfaceRec& sf, V3 o, V3 d, V3 inv, MeshHit& out, const Spill& spill PROF_ARG) {
+	float nr, fr;
+	if (!aabb_test_inv(sf.bmin, sf.bmax, o, inv, nr, fr)) return false;
+	return mesh_traverse_m<MODE, PB>(G, sf, nr, fr, o, d, out, spill PROF_PASS);
 }
 
 // Closest hit record: what the shading phase needs to rebuild everything else.
@@ -301,7 +308,7 @@ DEV bool scene_traverse(const DevScene& S, const Geoms& g, V3 o, V3 d, SceneHit&
 		int hit_surface = -1;
 		for (int s = 0; s < M.n_surfaces; s++) {
 			MeshHit h;
-			if (!mesh_traverse_m<MODE, 4>(g, S.surfaces[M.first_surface + s], lo, ld, inv, h, spill PROF_PASS)) continue;
+			if (!mesh_intersect_m<MODE, 4>(g, S.surfaces[M.first_surface + s], lo, ld, inv, h, spill PROF_PASS)) continue;
 			if (h.t < nearest.t || !(nearest.t >= 0)) { nearest = h; hit_surface = M.first_surface + s; }
 		}
 		if (!(nearest.t >= 0)) continue;
@@ -323,9 +330,6 @@ DEV bool scene_traverse(const DevScene& S, const Geoms& g, V3 o, V3 d, SceneHit&
 // each list is traversed with full waves. Per ray the arithmetic is unchanged; the closest hit is the minimum over
 // models of the world distance, ties going to the model visited first (renderer.cpp:663-669), which is evaluated
 // here as (distance, surface id) order because surface ids grow with the visit order.
-#ifndef PTX_INLINE_MIN
-#define PTX_INLINE_MIN 32
-#endif
 // renderer::intersect(shadow ray).has_hit() (renderer.cpp:509-511, intersection_worker.cpp:58-61): the reference finds the closest
 // hit and then only asks whether there is one, so the sweep may stop at the first model that reports a hit.
 template <int MODE>
@@ -349,16 +353,13 @@ DEV bool scene_occluded(const DevScene& S, const Geoms& g, V3 o, V3 d, const Spi
 		if (!aabb_test_inv(M.bmin, M.bmax, lo, inv, nr, fr)) continue;
 		for (int s = 0; s < M.n_surfaces; s++) {
 			MeshHit h;
-			if (!mesh_traverse_m<MODE, 4>(g, S.surfaces[M.first_surface + s], lo, ld, inv, h, spill PROF_PASS)) continue;
+			if (!mesh_intersect_m<MODE, 4>(g, S.surfaces[M.first_surface + s], lo, ld, inv, h, spill PROF_PASS)) continue;
 			if (length(mulmv(M.basis, ld * h.t)) >= 0) return true;   // model.cpp:62-63: a hit whose world distance is not NaN
 		}
 	}
 	return false;
 }
 
-constexpr uint32_t kInlineMin = PTX_INLINE_MIN;        // lanes of a wave-iteration that make a model worth traversing on the spot
-constexpr uint32_t kListCap = (kChunk / 64u) * (kInlineMin - 1u) + 16u;   // entries a list can receive per chunk (kChunk / 64 iterations)
-constexpr int kMaxDeferModels = 64;        // per-model list lengths live in the lanes of one VGPR
 
 // Closest hit inside ONE model for a lane that is known to enter its box: scene::model::intersect (model.cpp:27-63)
 template <int MODE, int PB>
@@ -369,7 +370,7 @@ DEV bool model_traverse(const DevScene& S, const Geoms& g, const ModelRec& M, V3
 	int hit_surface = -1;
 	for (int k = 0; k < M.n_surfaces; k++) {
 		MeshHit h;
-		if (!mesh_traverse_m<MODE, PB>(g, S.surfaces[M.first_surface + k], lo, ld, inv, h, spill PROF_PASS)) continue;
+		if (!mesh_intersect_m<MODE, PB>(g, S.surfaces[M.first_surface + k], lo, ld, inv, h, spill PROF_PASS)) continue;
 		if (h.t < nearest.t || !(nearest.t >= 0)) { nearest = h; hit_surface = M.first_surface + k; }
 	}
 	if (!(nearest.t >= 0)) return false;
@@ -377,6 +378,23 @@ DEV bool model_traverse(const DevScene& S, const Geoms& g, const ModelRec& M, V3
 	if (!(wd >= 0)) return false;
 	surf = hit_surface; tri = nearest.tri; b1 = nearest.b1; b2 = nearest.b2;
 	return true;
+}
+
+// SURF kernels set aside single SURFACES instead of whole models (a Sponza-class model has two dozen of them, each entered by
+// a handful of the wave's rays). The running closest hit of a ray then receives (model, surface) candidates in any order —
+// inline ones during the sweep, set-aside ones later. scene::model::intersect keeps, per model, the smallest LOCAL t (first
+// surface wins ties, model.cpp:47-55); renderer::intersect keeps, over models, the smallest WORLD distance (first model wins
+// ties, renderer.cpp:666-669). Hence: against a candidate of the same model compare local t, otherwise world distance.
+struct Best { float wd, tl; int surf, model; uint32_t tri; float b1, b2; };
+DEV void best_reset(Best& b) { b.wd = -1.0f; b.tl = -1.0f; b.surf = -1; b.model = -1; b.tri = 0; b.b1 = 0; b.b2 = 0; }
+DEV bool best_offer(Best& b, const ModelRec& M, int model, V3 ld, int surf, const MeshHit& h) {
+	const float wd = length(mulmv(M.basis, ld * h.t));   // local -> world distance (model.cpp:62-63)
+	if (!(wd >= 0)) return false;
+	bool win;
+	if (b.surf >= 0 && b.model == model) win = h.t < b.tl || (h.t == b.tl && surf < b.surf);
+	else win = b.surf < 0 || wd < b.wd || (wd == b.wd && model < b.model);
+	if (win) { b.wd = wd; b.tl = h.t; b.surf = surf; b.model = model; b.tri = h.tri; b.b1 = h.b1; b.b2 = h.b2; }
+	return win;
 }
 
 struct Surf { V3 pos, nrm, tan; float u, v; };
@@ -737,7 +755,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 //   EXTEND: (generate or) load ray -> closest hit -> 16-byte hit record        (traversal state only in registers)
 //   SHADE : load ray + hit + path state -> BSDF, radiance, next ray, shadow request -> compacted writes (no traversal)
 //   SHADOW: load request -> any hit? -> add the sun contribution / resolve a pending shadow catcher   (SUN variants)
-template <int MODE, bool SUN, bool ALPHA, bool TEX, bool WORKER>
+template <int MODE, bool SUN, bool ALPHA, bool TEX, bool WORKER, bool SURF>
 __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParams P, PassBuffers B, const ModelRec* __restrict__ t_models, const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
 	DevScene S = S0;
 	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;  // see struct Tables
@@ -746,11 +764,11 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave_slot = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	// wave-private streams: 2 ray buffers x 4 float4 arrays x kChunk entries, then 1 hit array
-	float4* qbase = B.queues + (size_t)wave_slot * (kQueueFloat4PerWave);
+	float4* qbase = B.queues + (size_t)wave_slot * B.queue_stride;
 	float4* hbuf = qbase + 2u * 4u * kChunk;
-	float* hdist = reinterpret_cast<float*>(hbuf + kChunk);                 // [kChunk] world distance of the current best hit (deferral)
-	float4* sreq = hbuf + kChunk + kChunk / 4u;                              // [3][kChunk] shadow requests: (origin, target) (dir, kind) (x, path id)
-	float4* lists = sreq + 3u * kChunk;                                      // [n_models][2][kListCap]: (local origin, ray index), (local dir, -)
+	float2* hdist = reinterpret_cast<float2*>(hbuf + kChunk);               // [kChunk] (world distance, local t) of the current best hit (deferral)
+	float4* sreq = hbuf + kChunk + kChunk / 2u;                              // [3][kChunk] shadow requests: (origin, target) (dir, kind) (x, path id)
+	float4* lists = sreq + 3u * kChunk;                                      // [units][2][kListCap]: (local origin, ray index), (local dir, -); units = models, or surfaces (SURF)
 	const Spill spill{B.spill + (size_t)wave_slot * (kSpillStack * 64) + lane};
 	uint32_t rays = 0;
 #ifdef PTX_PROF
@@ -790,9 +808,9 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 
 			// ---------------- EXTEND
 			// lists live in the unused part of the wave's stream area: hdist (kChunk words) + n_models lists
-			const bool defer = S.n_models <= kMaxDeferModels && S.n_models > 1 &&
-			                   (uint32_t)S.n_models * 2u * kListCap + kChunk / 4u <= kQueueFloat4PerWave - 12u * kChunk;
-			uint32_t list_len = 0;   // lane m: entries in model m's deferred list
+			const bool defer = SURF ? (S.n_surfaces >= 1 && S.n_surfaces <= (uint32_t)kMaxDeferModels)
+			                        : (S.n_models > 1 && S.n_models <= kMaxDeferModels);   // the list lengths live in the 64 lanes of one VGPR
+			uint32_t list_len = 0;   // lane u: entries in the deferred list of unit u (model, or surface in SURF kernels)
 			for (uint32_t base = 0; base < n_in; base += 64) {
 				const uint32_t i = base + lane;
 				const bool active = i < n_in;
@@ -817,7 +835,56 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 				}
 				SceneHit h;
 				if (!defer) { if (active) scene_traverse<MODE>(S, g, o, d, h, spill); }
-				else {
+				else if constexpr (SURF) {
+					// renderer::intersect's model loop / model::intersect's surface loop with the rarely entered SURFACES set aside
+					Best bh;
+					best_reset(bh);
+					uint32_t cur_space = 0xFFFFFFFFu;
+					V3 lo = o, ld = d, inv = d;
+					for (int m = 0; m < S.n_models; m++) {
+						const ModelRec& M = S.models[m];
+						const uint32_t spc = S.model_space[m];
+						if (active) PROF(1);
+						if (spc != cur_space) {
+							if (active) PROF(2);
+							const SpaceRec& SP = S.spaces[spc];
+							lo = mulmv(SP.inv_basis, o) + mk(SP.inv_origin[0], SP.inv_origin[1], SP.inv_origin[2]);
+							ld = normalize(mulmv(SP.inv_basis, d));
+							inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+							cur_space = spc;
+						}
+						float nr, fr;
+						const bool enters = active && aabb_test_inv(M.bmin, M.bmax, lo, inv, nr, fr);   // model box first (model.cpp:38-40)
+						if (__ballot(enters) == 0) continue;
+						for (int k = 0; k < M.n_surfaces; k++) {
+							const int u = M.first_surface + k;
+							const SurfaceRec& sf = S.surfaces[u];
+							const bool ent = enters && aabb_test_inv(sf.bmin, sf.bmax, lo, inv, nr, fr);
+							const uint64_t em = __ballot(ent);
+							if (em == 0) continue;
+							const uint32_t cnt = (uint32_t)__popcll(em);
+							if (cnt >= kInlineMin) {
+								if (ent) {
+									PROF(3);
+									MeshHit mh;
+									if (mesh_traverse_m<MODE, 4>(g, sf, nr, fr, lo, ld, mh, spill PROF_PASS)) best_offer(bh, M, m, ld, u, mh);
+								}
+							} else {
+								const uint32_t len = __builtin_amdgcn_readlane(list_len, u);
+								if (ent) {
+									PROF(14);
+									const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+									float4* L0 = lists + (size_t)u * 2u * kListCap;
+									L0[len + r] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(i));
+									L0[kListCap + len + r] = make_float4(ld.x, ld.y, ld.z, 0.f);
+								}
+								list_len = (int)lane == u ? len + cnt : list_len;
+							}
+						}
+					}
+					h.dist = bh.wd; h.surface = bh.surf; h.tri = bh.tri; h.b1 = bh.b1; h.b2 = bh.b2;
+					if (active) hdist[i] = make_float2(bh.wd, bh.tl);
+				} else {
 					// renderer::intersect's model loop with the rarely entered models set aside
 					h.dist = -1.0f; h.surface = -1; h.tri = 0; h.b1 = 0; h.b2 = 0;
 					uint32_t cur_space = 0xFFFFFFFFu;
@@ -860,11 +927,45 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 						}
 					}
 				}
-				if (active) { hbuf[i] = make_float4(__int_as_float(h.surface), __uint_as_float(h.tri), h.b1, h.b2); if (defer) hdist[i] = h.dist; }
+				if (active) { hbuf[i] = make_float4(__int_as_float(h.surface), __uint_as_float(h.tri), h.b1, h.b2); if (defer && !SURF) hdist[i].x = h.dist; }
 			}
 			if (defer) {
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				if constexpr (SURF) {
+					// the lists, surface by surface, with full waves
+					for (int u = 0; u < (int)S.n_surfaces; u++) {
+						const uint32_t len = __builtin_amdgcn_readlane(list_len, u);
+						if (len == 0) continue;
+						const SurfaceRec& sf = S.surfaces[u];
+						const int m = (int)sf.model;
+						const ModelRec& M = S.models[m];
+						const float4* L0 = lists + (size_t)u * 2u * kListCap;
+						for (uint32_t base = 0; base < len; base += 64) {
+							if (base + lane < len) {
+								PROF(8);
+								const float4 e0 = L0[base + lane], e1 = L0[kListCap + base + lane];
+								const uint32_t i = __float_as_uint(e0.w);
+								const float4 hr = hbuf[i];                       // current best of this ray: issued before the traversal
+								const float2 hd = hdist[i];
+								const V3 lo = mk(e0.x, e0.y, e0.z), ld = mk(e1.x, e1.y, e1.z);
+								const V3 inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+								MeshHit mh;
+								if (mesh_intersect_m<MODE, 10>(g, sf, lo, ld, inv, mh, spill PROF_PASS)) {
+									Best b;
+									b.surf = __float_as_int(hr.x); b.tri = __float_as_uint(hr.y); b.b1 = hr.z; b.b2 = hr.w; b.wd = hd.x; b.tl = hd.y;
+									b.model = b.surf >= 0 ? (int)S.surfaces[b.surf].model : -1;   // per-lane table read, only on a hit
+									if (best_offer(b, M, m, ld, u, mh)) {
+										hbuf[i] = make_float4(__int_as_float(b.surf), __uint_as_float(b.tri), b.b1, b.b2);
+										hdist[i] = make_float2(b.wd, b.tl);
+									}
+								}
+							}
+						}
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					}
+				} else
 				// the lists, model by model, with full waves
 				for (int m = 0; m < S.n_models; m++) {
 					const uint32_t len = __builtin_amdgcn_readlane(list_len, m);
@@ -876,7 +977,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 							PROF(8);
 							const float4 e0 = L0[base + lane], e1 = L0[kListCap + base + lane];
 							const uint32_t i = __float_as_uint(e0.w);
-							const float bd = hdist[i];                       // current best of this ray: issued before the traversal
+							const float bd = hdist[i].x;                     // current best of this ray: issued before the traversal
 							const int bs = __float_as_int(hbuf[i].x);
 							const V3 lo = mk(e0.x, e0.y, e0.z), ld = mk(e1.x, e1.y, e1.z);
 							const V3 inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
@@ -884,7 +985,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 							if (model_traverse<MODE, 10>(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill PROF_PASS) &&
 							    (wd < bd || !(bd >= 0) || (wd == bd && surf < bs))) {
 								hbuf[i] = make_float4(__int_as_float(surf), __uint_as_float(tri), b1, b2);
-								hdist[i] = wd;
+								hdist[i].x = wd;
 							}
 						}
 					}
@@ -955,6 +1056,85 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 
 			// ---------------- SHADOW: any-hit sweep over the requests of this step
 			if constexpr (SUN) {
+				constexpr uint32_t kOccluded = 0x80000000u;
+				const bool listed = SURF && defer && n_sh > 0;
+				if constexpr (SURF) if (listed) {
+					// the requests go through the same inline-or-set-aside classification as the extend sweep; a request is marked
+					// occluded (kOccluded in its kind word) by whichever surface reports a hit first, and entries of an already
+					// occluded request are passed over
+					list_len = 0;
+					for (uint32_t base = 0; base < n_sh; base += 64) {
+						const uint32_t j = base + lane;
+						const bool active = j < n_sh;
+						V3 o = {0, 0, 0}, d = {0, 0, 1};
+						if (active) { const float4 r0 = sreq[j], r1 = sreq[kChunk + j]; o = mk(r0.x, r0.y, r0.z); d = mk(r1.x, r1.y, r1.z); }
+						bool occ = false;
+						uint32_t cur_space = 0xFFFFFFFFu;
+						V3 lo = o, ld = d, inv = d;
+						for (int m = 0; m < S.n_models; m++) {
+							const ModelRec& M = S.models[m];
+							const uint32_t spc = S.model_space[m];
+							if (spc != cur_space) {
+								const SpaceRec& SP = S.spaces[spc];
+								lo = mulmv(SP.inv_basis, o) + mk(SP.inv_origin[0], SP.inv_origin[1], SP.inv_origin[2]);
+								ld = normalize(mulmv(SP.inv_basis, d));
+								inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+								cur_space = spc;
+							}
+							float nr, fr;
+							const bool enters = active && !occ && aabb_test_inv(M.bmin, M.bmax, lo, inv, nr, fr);
+							if (__ballot(enters) == 0) continue;
+							for (int k = 0; k < M.n_surfaces; k++) {
+								const int u = M.first_surface + k;
+								const SurfaceRec& sf = S.surfaces[u];
+								const bool ent = enters && !occ && aabb_test_inv(sf.bmin, sf.bmax, lo, inv, nr, fr);
+								const uint64_t em = __ballot(ent);
+								if (em == 0) continue;
+								const uint32_t cnt = (uint32_t)__popcll(em);
+								if (cnt >= kInlineMin) {
+									if (ent) {
+										MeshHit mh;
+										if (mesh_traverse_m<MODE, 4>(g, sf, nr, fr, lo, ld, mh, spill PROF_PASS) && length(mulmv(M.basis, ld * mh.t)) >= 0) occ = true;
+									}
+								} else {
+									const uint32_t len = __builtin_amdgcn_readlane(list_len, u);
+									if (ent) {
+										const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+										float4* L0 = lists + (size_t)u * 2u * kListCap;
+										L0[len + r] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(j));
+										L0[kListCap + len + r] = make_float4(ld.x, ld.y, ld.z, 0.f);
+									}
+									list_len = (int)lane == u ? len + cnt : list_len;
+								}
+							}
+						}
+						if (active && occ) { uint32_t* kw = reinterpret_cast<uint32_t*>(sreq + kChunk + j) + 3; *kw = *kw | kOccluded; }
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					for (int u = 0; u < (int)S.n_surfaces; u++) {
+						const uint32_t len = __builtin_amdgcn_readlane(list_len, u);
+						if (len == 0) continue;
+						const SurfaceRec& sf = S.surfaces[u];
+						const ModelRec& M = S.models[sf.model];
+						const float4* L0 = lists + (size_t)u * 2u * kListCap;
+						for (uint32_t base = 0; base < len; base += 64) {
+							if (base + lane < len) {
+								const float4 e0 = L0[base + lane], e1 = L0[kListCap + base + lane];
+								const uint32_t j = __float_as_uint(e0.w);
+								uint32_t* kw = reinterpret_cast<uint32_t*>(sreq + kChunk + j) + 3;
+								if (!(*kw & kOccluded)) {
+									const V3 lo = mk(e0.x, e0.y, e0.z), ld = mk(e1.x, e1.y, e1.z);
+									const V3 inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+									MeshHit mh;
+									if (mesh_intersect_m<MODE, 10>(g, sf, lo, ld, inv, mh, spill PROF_PASS) && length(mulmv(M.basis, ld * mh.t)) >= 0) *kw = *kw | kOccluded;
+								}
+							}
+						}
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					}
+				}
 				for (uint32_t base = 0; base < n_sh; base += 64) {
 					const uint32_t j = base + lane;
 					bool through = false;
@@ -964,8 +1144,9 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 						const float4 r0 = sreq[j], r1 = sreq[kChunk + j], r2 = sreq[2 * kChunk + j];
 						target = __float_as_uint(r0.w); id = __float_as_uint(r2.w);
 						x = mk(r2.x, r2.y, r2.z);
-						const bool occluded = scene_occluded<MODE>(S, g, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), spill);
-						if (__float_as_uint(r1.w) == REQ_ADD) {
+						const bool occluded = listed ? (__float_as_uint(r1.w) & kOccluded) != 0
+						                             : scene_occluded<MODE>(S, g, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), spill);
+						if ((__float_as_uint(r1.w) & ~kOccluded) == REQ_ADD) {
 							if (!occluded) {
 								if (target == 0xFFFFFFFFu) {
 									float4 v = B.sample_rad[id];
@@ -1096,35 +1277,41 @@ static hipError_t set_lds(const void* fn, size_t bytes) {
 	return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int MODE, bool SUN, bool ALPHA, bool TEX, bool WORKER = false>
+template <int MODE, bool SURF, bool SUN, bool ALPHA, bool TEX, bool WORKER = false>
 static hipError_t launch_pass_variant(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
 	if (MODE != MODE_GLOBAL) {
-		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<MODE, SUN, ALPHA, TEX, WORKER>), lds_bytes);
+		hipError_t e = set_lds(reinterpret_cast<const void*>(&k_render_pass<MODE, SUN, ALPHA, TEX, WORKER, SURF>), lds_bytes);
 		if (e != hipSuccess) return e;
 	}
-	hipLaunchKernelGGL((k_render_pass<MODE, SUN, ALPHA, TEX, WORKER>), dim3(grid), dim3(kBlock), MODE != MODE_GLOBAL ? lds_bytes : 0, stream, S, P, B, S.models, S.surfaces, S.spaces, S.model_space);
+	hipLaunchKernelGGL((k_render_pass<MODE, SUN, ALPHA, TEX, WORKER, SURF>), dim3(grid), dim3(kBlock), MODE != MODE_GLOBAL ? lds_bytes : 0, stream, S, P, B, S.models, S.surfaces, S.spaces, S.model_space);
 	return hipGetLastError();
 }
 
-// Kernel variants: {where the geometry lives} x {sun shadow rays} x {opacity / shadow-catcher pass-through}; textured scenes
-// and the worker estimator get one variant with everything compiled in (sun code is skipped at run time without a sun).
-template <int MODE>
+// Kernel variants: {where the geometry lives} x {units set aside: models | surfaces} x {sun shadow rays} x {opacity / shadow-
+// catcher pass-through}; textured scenes and the worker estimator get one variant with everything compiled in (sun code is
+// skipped at run time without a sun).
+template <int MODE, bool SURF>
 static hipError_t launch_pass_mode(const DevScene& S, const RenderParams& P, const PassBuffers& B, size_t lds_bytes, int grid, hipStream_t stream) {
 	const bool sun = S.sun.present != 0, alpha = S.any_alpha != 0;
 	if (P.integrator == 1u)
-		return S.any_texture ? launch_pass_variant<MODE, true, true, true, true>(S, P, B, lds_bytes, grid, stream)
-		                     : launch_pass_variant<MODE, true, true, false, true>(S, P, B, lds_bytes, grid, stream);
-	if (S.any_texture) return launch_pass_variant<MODE, true, true, true>(S, P, B, lds_bytes, grid, stream);
-	if (sun) return alpha ? launch_pass_variant<MODE, true, true, false>(S, P, B, lds_bytes, grid, stream)
-	                      : launch_pass_variant<MODE, true, false, false>(S, P, B, lds_bytes, grid, stream);
-	return alpha ? launch_pass_variant<MODE, false, true, false>(S, P, B, lds_bytes, grid, stream)
-	             : launch_pass_variant<MODE, false, false, false>(S, P, B, lds_bytes, grid, stream);
+		return S.any_texture ? launch_pass_variant<MODE, SURF, true, true, true, true>(S, P, B, lds_bytes, grid, stream)
+		                     : launch_pass_variant<MODE, SURF, true, true, false, true>(S, P, B, lds_bytes, grid, stream);
+	if (S.any_texture) return launch_pass_variant<MODE, SURF, true, true, true>(S, P, B, lds_bytes, grid, stream);
+	if (sun) return alpha ? launch_pass_variant<MODE, SURF, true, true, false>(S, P, B, lds_bytes, grid, stream)
+	                      : launch_pass_variant<MODE, SURF, true, false, false>(S, P, B, lds_bytes, grid, stream);
+	return alpha ? launch_pass_variant<MODE, SURF, false, true, false>(S, P, B, lds_bytes, grid, stream)
+	             : launch_pass_variant<MODE, SURF, false, false, false>(S, P, B, lds_bytes, grid, stream);
 }
 hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, int mode, size_t lds_bytes, int grid,
                               hipStream_t stream) {
-	if (mode == MODE_LDS) return launch_pass_mode<MODE_LDS>(S, P, B, lds_bytes, grid, stream);
-	if (mode == MODE_HYBRID) return launch_pass_mode<MODE_HYBRID>(S, P, B, lds_bytes, grid, stream);
-	return launch_pass_mode<MODE_GLOBAL>(S, P, B, lds_bytes, grid, stream);
+	if (B.surface_units) {
+		if (mode == MODE_LDS) return launch_pass_mode<MODE_LDS, true>(S, P, B, lds_bytes, grid, stream);
+		if (mode == MODE_HYBRID) return launch_pass_mode<MODE_HYBRID, true>(S, P, B, lds_bytes, grid, stream);
+		return launch_pass_mode<MODE_GLOBAL, true>(S, P, B, lds_bytes, grid, stream);
+	}
+	if (mode == MODE_LDS) return launch_pass_mode<MODE_LDS, false>(S, P, B, lds_bytes, grid, stream);
+	if (mode == MODE_HYBRID) return launch_pass_mode<MODE_HYBRID, false>(S, P, B, lds_bytes, grid, stream);
+	return launch_pass_mode<MODE_GLOBAL, false>(S, P, B, lds_bytes, grid, stream);
 }
 hipError_t launch_resolve(const float4* sample_rad, float4* accum, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream) {
 	hipLaunchKernelGGL(k_resolve, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, sample_rad, accum, n_pixels, pass_spp);

@@ -16,7 +16,17 @@ constexpr int kBlock = PTX_BLOCK;  // threads per workgroup (one workgroup per C
 #endif
 constexpr uint32_t kChunk = PTX_CHUNK; // camera paths a wave takes per counter fetch (32 wave-iterations). Measured with 64 spp per launch: 512 -7 %, 1024 0, 2048 +5.6 %, 4096 +6.3 % on Cornell; 4096 -12 % on the open plaza scene
 // wave-private stream space, in float4
-constexpr uint32_t kQueueFloat4PerWave = 22u * kChunk;  // 2 x 4 ray arrays + hit records (9), hit distances (1/4), shadow requests (3), the rest: deferred-model lists
+// Per-wave stream area in float4: 2 x 4 ray arrays + hit records (9 kChunk), hit distances (1/2), shadow requests (3), then one
+// deferred list (2 x kListCap float4) per unit that can be set aside: per model, or per surface in the SURF kernels (<= 64 units:
+// the list lengths live in the lanes of one VGPR).
+#ifndef PTX_INLINE_MIN
+#define PTX_INLINE_MIN 32
+#endif
+constexpr uint32_t kInlineMin = PTX_INLINE_MIN;        // lanes of a wave-iteration that make a unit worth traversing on the spot
+constexpr uint32_t kListCap = (kChunk / 64u) * (kInlineMin - 1u) + 16u;   // entries a list can receive per chunk (kChunk / 64 iterations)
+constexpr int kMaxDeferModels = 64;
+constexpr uint32_t kQueueFixedFloat4 = 12u * kChunk + kChunk / 2u;
+inline uint32_t queue_float4_per_wave(uint32_t n_units) { return kQueueFixedFloat4 + (n_units <= (uint32_t)kMaxDeferModels ? n_units : 0u) * 2u * kListCap; }
 constexpr uint32_t kSpillWords = 24u * 64u;  // uint2 per wave: kSpillStack levels x 64 lanes
 
 // Device view of a FlatScene (all pointers are device pointers).
@@ -71,7 +81,9 @@ struct RenderParams {
 constexpr int kProfRegions = 16;   // PTX_PROF builds only: (wave-level trips, active lanes) per code region
 
 struct PassBuffers {
-	float4* queues;                   // [n_wave_slots][kQueueFloat4PerWave]
+	float4* queues;                   // [n_wave_slots][queue_stride]
+	uint32_t queue_stride;            // float4 per wave: queue_float4_per_wave(units)
+	uint32_t surface_units;           // 1: the SURF kernels (single surfaces are set aside), 0: whole models
 	float4* sample_rad;               // [pass_spp][n_pixels]
 	uint2* spill;                     // [n_wave_slots][kSpillWords]: traversal-stack overflow, lane-interleaved
 	unsigned long long* chunk_counter; // paths handed out so far; zeroed before each pass

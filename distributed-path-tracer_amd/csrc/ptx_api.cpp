@@ -430,7 +430,15 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 
 	const int grid = c->n_cu;
 	const size_t n_slots = (size_t)grid * (kBlock / 64);
-	HIP_TRY(c->queues.ensure(n_slots * (size_t)kQueueFloat4PerWave * sizeof(float4)));
+	// Units the kernels may set aside: whole models, or — when some model has many surfaces (a Sponza-class mesh) — single
+	// surfaces. PTX_SURFACE_UNITS=0/1 overrides the choice (measurement).
+	const uint32_t n_surf = (uint32_t)sc->host.surfaces.size(), n_mod = (uint32_t)sc->host.models.size();
+	int32_t max_per_model = 0;
+	for (const ModelRec& mr : sc->host.models) max_per_model = std::max(max_per_model, mr.n_surfaces);
+	bool surface_units = max_per_model >= 8 && n_surf <= (uint32_t)kMaxDeferModels;   // measured: +49 % on a 24-surface model, -2..-7 % on scenes of 1-3 surfaces per model
+	if (const char* e = getenv("PTX_SURFACE_UNITS")) surface_units = e[0] == '1' && n_surf <= (uint32_t)kMaxDeferModels;
+	const uint32_t queue_stride = queue_float4_per_wave(surface_units ? n_surf : n_mod);
+	HIP_TRY(c->queues.ensure(n_slots * (size_t)queue_stride * sizeof(float4)));
 	HIP_TRY(c->sample_rad.ensure((size_t)pass_spp * n_pixels * sizeof(float4)));
 	HIP_TRY(c->counters.ensure(1024));   // [0] chunk counter, [16] ray counter, [64..] PTX_PROF region counters
 	HIP_TRY(c->spill.ensure(n_slots * (size_t)kSpillWords * sizeof(uint2)));
@@ -453,7 +461,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 			HIP_TRY(hipEventCreate(&ev));
 			c->events.push_back(ev);
 		}
-	PassBuffers B{(float4*)c->queues.p, (float4*)c->sample_rad.p, (uint2*)c->spill.p, chunk_counter, ray_counter};
+	PassBuffers B{(float4*)c->queues.p, queue_stride, surface_units ? 1u : 0u, (float4*)c->sample_rad.p, (uint2*)c->spill.p, chunk_counter, ray_counter};
 	for (uint32_t p = 0; p < n_pass; p++) {
 		RenderParams P{};
 		P.W = cfg->W; P.H = cfg->H; P.x0 = x0; P.y0 = y0; P.w = w; P.h = h;

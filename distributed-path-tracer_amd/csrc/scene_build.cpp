@@ -272,6 +272,7 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 			for (int r = 0; r < 3; r++) mr.nmat[3 * c + r] = mr.inv_basis[3 * r + c];
 		mr.first_surface = s.model_surf[2 * mi];
 		mr.n_surfaces = s.model_surf[2 * mi + 1];
+		for (int32_t k = 0; k < mr.n_surfaces; k++) s.surfaces[mr.first_surface + k].model = (uint32_t)mi;
 		Box b;
 		box_reset(b);
 		for (int32_t k = 0; k < mr.n_surfaces; k++) {

@@ -354,6 +354,21 @@ def test_all_three_residency_modes_agree(ptx, ctx, ora, monkeypatch, switch, mod
     np.testing.assert_array_equal(got_w, ref_w)
 
 
+@pytest.mark.parametrize("units", ["0", "1"])
+def test_model_and_surface_deferral_units_agree(ptx, ctx, scene, monkeypatch, units):
+    """The kernels that set aside whole models and the ones that set aside single surfaces (chosen per scene; forced here) return
+    bitwise the same frames on the headline scene and on the 24-surface model."""
+    from conftest import CORNELL, product_from_dict
+    ref, _ = scene.render(128, 72, 4, 8)
+    d = _proc().atrium_scene(2)
+    aref, _ = product_from_dict(ptx, ctx, d).render(96, 54, 3, 6)
+    monkeypatch.setenv("PTX_SURFACE_UNITS", units)
+    got, _ = ptx.Scene.load_gltf(ctx, CORNELL).render(128, 72, 4, 8)
+    np.testing.assert_array_equal(got, ref)
+    agot, _ = product_from_dict(ptx, ctx, d).render(96, 54, 3, 6)
+    np.testing.assert_array_equal(agot, aref)
+
+
 def test_cornell_on_global_memory_kernels(ptx, ctx, scene, monkeypatch):
     """MODE_LDS vs MODE_GLOBAL on the headline scene: bitwise equal frames and hit records."""
     from conftest import CORNELL
