@@ -45,32 +45,41 @@ constexpr float kEps = 0.0001f;                        // math::epsilon (math/ma
 constexpr double kPi = 3.14159265358979323846;         // math::pi is double (math/math.hpp:18)
 constexpr double kInvSqrt3 = 1.0 / 1.7320508075688772; // 1 / math::sqrt3 (util/rand_cone_vec.cpp:23)
 
-struct V3 { float x, y, z; };
-DEV V3 mk(float x, float y, float z) { return {x, y, z}; }
-DEV V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-DEV V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-DEV V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
-DEV V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-DEV V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
-DEV V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
-DEV V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
-DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                    // math/vec3.inl:236
-DEV V3 cross(V3 l, V3 r) { return {(l.y * r.z) - (l.z * r.y), (l.z * r.x) - (l.x * r.z), (l.x * r.y) - (l.y * r.x)}; }
+// 3-vectors keep (x, y) in one register pair so that component-wise + - * compile to packed fp32 instructions (one
+// v_pk_* for x and y, one scalar op for z): the same IEEE operation per component, two per issue slot.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct V3 {
+	union { struct { float x, y; }; f2 xy; };
+	float z;
+};
+DEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEV V3 mk2(f2 xy, float z) { V3 r; r.xy = xy; r.z = z; return r; }
+DEV f2 bc2(float a) { return (f2){a, a}; }
+DEV V3 operator+(V3 a, V3 b) { return mk2(a.xy + b.xy, a.z + b.z); }
+DEV V3 operator-(V3 a, V3 b) { return mk2(a.xy - b.xy, a.z - b.z); }
+DEV V3 operator*(V3 a, V3 b) { return mk2(a.xy * b.xy, a.z * b.z); }
+DEV V3 operator*(V3 a, float s) { return mk2(a.xy * bc2(s), a.z * s); }
+DEV V3 operator*(float s, V3 a) { return mk2(bc2(s) * a.xy, s * a.z); }
+DEV V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+DEV V3 operator-(V3 a) { return mk2(-a.xy, -a.z); }
+DEV float dot(V3 a, V3 b) { const f2 p = a.xy * b.xy; return p.x + p.y + a.z * b.z; }     // math/vec3.inl:236
+DEV V3 cross(V3 l, V3 r) { return mk((l.y * r.z) - (l.z * r.y), (l.z * r.x) - (l.x * r.z), (l.x * r.y) - (l.y * r.x)); }
 DEV float length(V3 a) { return sqrtf(dot(a, a)); }
 DEV V3 normalize(V3 a) { return a * (1.0f / length(a)); }                                  // math/vec3.inl:251
 DEV float pmax(float a, float b) { return b > a ? b : a; }                                 // math::max (NaN-asymmetric), math.inl:169
 DEV float pmin(float a, float b) { return b < a ? b : a; }                                 // math::min, math.inl:179
 DEV float lerpf(float a, float b, float w) { return a + (b - a) * w; }                     // math.inl:164
 DEV float clampf(float x, float lo, float hi) { return pmin(pmax(x, lo), hi); }            // math.inl:154
-DEV V3 lerp3(V3 a, V3 b, float w) { return {lerpf(a.x, b.x, w), lerpf(a.y, b.y, w), lerpf(a.z, b.z, w)}; }
-DEV V3 lerp3(V3 a, V3 b, V3 w) { return {lerpf(a.x, b.x, w.x), lerpf(a.y, b.y, w.y), lerpf(a.z, b.z, w.z)}; }
+DEV V3 lerp3(V3 a, V3 b, float w) { return a + (b - a) * w; }
+DEV V3 lerp3(V3 a, V3 b, V3 w) { return a + (b - a) * w; }
 DEV V3 reflect3(V3 incident, V3 normal) { return incident - 2 * dot(normal, incident) * normal; }  // core/utils.hpp:38
 // math::pow(float, 5): std::pow promotes to double; x^5 by exact-ish double products, rounded once to float
 DEV float pow5(float x) { double d = (double)x; double d2 = d * d; return (float)(d2 * d2 * d); }
 DEV float sel3(V3 v, uint32_t axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 // column-major 3x3 (float[9] = x.xyz y.xyz z.xyz) times vector: each ROW dotted with v (math/mat3.inl:219-224)
 DEV V3 mulmv(const float* m, V3 v) {
-	return {m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z, m[2] * v.x + m[5] * v.y + m[8] * v.z};
+	const f2 c0 = {m[0], m[1]}, c1 = {m[3], m[4]}, c2 = {m[6], m[7]};
+	return mk2(c0 * bc2(v.x) + c1 * bc2(v.y) + c2 * bc2(v.z), m[2] * v.x + m[5] * v.y + m[8] * v.z);
 }
 
 // ------------------------------------------------------------------------------------ geometry access
@@ -106,7 +115,6 @@ struct Tables {
 // The record pairs the edge components so that the cofactors come out as (c1, -c2), (c4, -c4), (c6, -c5): a term the
 // reference subtracts is then added with its sign already flipped, and x + (-y) == x - y, -(x*y) == (-x)*y exactly.
 // Returns the distance, or -1 when the barycentric tests fail (a NaN from a zero determinant fails `t >= 0` later).
-typedef float f2 __attribute__((ext_vector_type(2)));
 DEV f2 swp(f2 a) { return __builtin_shufflevector(a, a, 1, 0); }
 DEV f2 bc(float a) { return (f2){a, a}; }
 struct PRay { f2 oyz, dyz; float ox, dx; };   // the local ray, arranged for tri_test_pk
