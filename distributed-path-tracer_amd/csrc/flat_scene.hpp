@@ -51,8 +51,10 @@ struct ModelRec {
 	float nmat[9];        // columns of transpose(inverse(basis))        — renderer.cpp:698
 	float bmin[3], bmax[3];  // model AABB in local space                 — model.cpp:13-18
 	int32_t first_surface, n_surfaces;
+	float pbmin[3], pbmax[3];  // the box grown by the reach of the +-epsilon barycentric slack: every point the triangle tests of this
+	                           // model can accept lies inside it (pruning of set-aside traversals, kernels.hip)
 };
-static_assert(sizeof(ModelRec) == 41 * 4, "ModelRec layout");
+static_assert(sizeof(ModelRec) == 47 * 4, "ModelRec layout");
 
 // ---- per-surface record (model::surface = mesh + material) ----
 struct SurfaceRec {
@@ -61,6 +63,7 @@ struct SurfaceRec {
 	uint32_t tri_base;       // global id of the mesh's triangle 0
 	uint32_t lds_root;       // index of the root in the LDS-resident node array, 0xFFFFFFFF when the surface is not resident
 	uint32_t model;          // the model this surface belongs to
+	float pbmin[3], pbmax[3];  // mesh AABB grown by the reach of the barycentric slack (see ModelRec)
 };
 
 // ---- material factors (core/material.hpp:11-17) and texture slots ----

@@ -369,6 +369,19 @@ DEV bool scene_occluded(const DevScene& S, const Geoms& g, V3 o, V3 d, const Spi
 }
 
 
+// Exact pruning of a set-aside traversal: every point a triangle test of the unit can accept lies inside its slack-grown box
+// (pbmin / pbmax, scene_build.cpp), so no hit of the unit is nearer than the ray's entry into that box. If even that entry —
+// as a world distance, shortened by 1e-4 relative to cover every rounding on the way — lies beyond the closest hit the ray
+// already has, no candidate of the unit can win (candidates win on `<`, or on `==` with a lower id) and the traversal is
+// skipped; the result is bitwise what it would have been.
+DEV bool cannot_win(const float* pbmin, const float* pbmax, const float* basis, V3 lo, V3 ld, V3 inv, float best_wd) {
+	if (!(best_wd >= 0)) return false;
+	float pn, pf;
+	if (!aabb_test_inv(pbmin, pbmax, lo, inv, pn, pf)) return true;    // misses even the grown box: nothing to find
+	if (!(pn > 0)) return false;
+	return length(mulmv(basis, ld * pn)) * 0.9999f > best_wd;
+}
+
 // Closest hit inside ONE model for a lane that is known to enter its box: scene::model::intersect (model.cpp:27-63)
 template <int MODE, int PB>
 DEV bool model_traverse(const DevScene& S, const Geoms& g, const ModelRec& M, V3 lo, V3 ld, V3 inv, float& wd, int& surf, uint32_t& tri,
@@ -959,7 +972,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 								const V3 lo = mk(e0.x, e0.y, e0.z), ld = mk(e1.x, e1.y, e1.z);
 								const V3 inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
 								MeshHit mh;
-								if (mesh_intersect_m<MODE, 10>(g, sf, lo, ld, inv, mh, spill PROF_PASS)) {
+								if (!cannot_win(sf.pbmin, sf.pbmax, M.basis, lo, ld, inv, hd.x) && mesh_intersect_m<MODE, 10>(g, sf, lo, ld, inv, mh, spill PROF_PASS)) {
 									Best b;
 									b.surf = __float_as_int(hr.x); b.tri = __float_as_uint(hr.y); b.b1 = hr.z; b.b2 = hr.w; b.wd = hd.x; b.tl = hd.y;
 									b.model = b.surf >= 0 ? (int)S.surfaces[b.surf].model : -1;   // per-lane table read, only on a hit
@@ -990,7 +1003,8 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 							const V3 lo = mk(e0.x, e0.y, e0.z), ld = mk(e1.x, e1.y, e1.z);
 							const V3 inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
 							float wd, b1, b2; int surf; uint32_t tri;
-							if (model_traverse<MODE, 10>(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill PROF_PASS) &&
+							if (!cannot_win(M.pbmin, M.pbmax, M.basis, lo, ld, inv, bd) &&
+							    model_traverse<MODE, 10>(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill PROF_PASS) &&
 							    (wd < bd || !(bd >= 0) || (wd == bd && surf < bs))) {
 								hbuf[i] = make_float4(__int_as_float(surf), __uint_as_float(tri), b1, b2);
 								hdist[i].x = wd;

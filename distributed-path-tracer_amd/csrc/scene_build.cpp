@@ -193,6 +193,18 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 			memcpy(&rec.p0, &gid, 4);
 			s.tri_isect.push_back(rec);
 		}
+		{   // a test accepts beta, gamma in [-eps, 1 + eps] (triangle.cpp:160-183): the accepted point (1-b-g) a + b B + g C lies within
+			// 2 eps max_edge of the triangle; 4 eps max_edge (and the eps the box is already padded with) bounds it with room to spare
+			float max_edge = 0;
+			for (int32_t t = 0; t < nt; t++)
+				for (int k = 0; k < 3; k++) {
+					const float* p = k == 0 ? pa[t].v : (k == 1 ? pb[t].v : pc[t].v);
+					const float* q = k == 0 ? pb[t].v : (k == 1 ? pc[t].v : pa[t].v);
+					max_edge = std::max(max_edge, std::sqrt((p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2])));
+				}
+			const float pad = 4 * kEps * max_edge + kEps;
+			for (int k = 0; k < 3; k++) { sr.pbmin[k] = sr.bmin[k] - pad; sr.pbmax[k] = sr.bmax[k] + pad; }
+		}
 		MeshBuilder mbuild{pa, pb, pc, {}, 0};
 		std::vector<uint32_t> all(nt);
 		for (int32_t t = 0; t < nt; t++) all[t] = (uint32_t)t;
@@ -281,6 +293,14 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 		}
 		memcpy(mr.bmin, b.lo, 12);
 		memcpy(mr.bmax, b.hi, 12);
+		Box pbx;   // union of the surfaces' slack-grown boxes
+		box_reset(pbx);
+		for (int32_t k = 0; k < mr.n_surfaces; k++) {
+			box_grow(pbx, s.surfaces[mr.first_surface + k].pbmin);
+			box_grow(pbx, s.surfaces[mr.first_surface + k].pbmax);
+		}
+		memcpy(mr.pbmin, pbx.lo, 12);
+		memcpy(mr.pbmax, pbx.hi, 12);
 	}
 	// distinct ray spaces (bitwise-equal inverse transforms)
 	s.spaces.clear();
