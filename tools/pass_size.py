@@ -9,7 +9,7 @@ ctx = ptx.Context(0)
 s = ptx.Scene.load_gltf(ctx, os.path.join(ROOT, "scenes/cornell-box/cornell.gltf"))
 W, H, SPP, B = 1920, 1080, 256, 8
 acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
-for pp in (4, 8, 16, 32, 64, 128):
+for pp in (8, 16, 64, 128, 256):
     s.render(W, H, pp, B, accum=acc, spp_per_pass=pp)
     torch.cuda.synchronize()
     t = time.perf_counter()
