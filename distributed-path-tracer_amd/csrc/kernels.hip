@@ -51,6 +51,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 struct V3 {
 	union { struct { float x, y; }; f2 xy; };
 	float z;
+	V3() = default;
+	DEV V3(float x_, float y_, float z_) { x = x_; y = y_; z = z_; }
 };
 DEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 DEV V3 mk2(f2 xy, float z) { V3 r; r.xy = xy; r.z = z; return r; }
