@@ -143,6 +143,7 @@ def lib():
         L.ptx_worker_event_load.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(RenderCfg), C.POINTER(WorkerEvent)]
         L.ptx_scene_from_arrays.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         L.ptx_scene_destroy.argtypes = [C.c_void_p]
+        L.ptx_scene_set_environment.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.ptx_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
         L.ptx_scene_get_array.restype = C.c_int64
         L.ptx_scene_get_array.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
@@ -316,6 +317,11 @@ class Scene:
         stats = dict(rays=st.rays, samples=st.samples, passes=st.passes, kernel_ms=st.kernel_ms) if want_stats else None
         return accum, stats
 
+    def set_environment(self, png_path, srgb=True):
+        """renderer::environment = image_texture::load(png_path, srgb): the miss colour becomes map(direction) * environment_factor.
+        None removes the map."""
+        _check(lib().ptx_scene_set_environment(self.h, os.fsencode(png_path) if png_path is not None else None, int(bool(srgb))))
+
     def intersect(self, origins, dirs, attributes=True):
         """Batch closest-hit. origins/dirs: [n,3] float32 numpy. Returns dict of numpy arrays."""
         o = np.ascontiguousarray(np.asarray(origins, np.float32).T)
@@ -366,6 +372,7 @@ class Renderer:
         self.thread_count = 0            # kept for interface parity; the GPU grid replaces the thread pool
         self.sample_count = 10000
         self.bounce_count = 4
+        self.environment = None          # path of a PNG environment map (the reference holds a loaded image::texture), sRGB-decoded
         self.environment_factor = (1.0, 1.0, 1.0)
         self.transparent_background = False
         self.camera_index = 0
@@ -385,6 +392,9 @@ class Renderer:
         if self.transparent_background or self.visualize_kd_tree_depth:
             raise PtxError(ERR_UNSUPPORTED, "transparent_background / visualize_kd_tree_depth are debug paths that are not built")
         W, H = self.resolution
+        if self.environment != getattr(self, "_env_set", None):
+            self._scene.set_environment(self.environment)
+            self._env_set = self.environment
         accum, self.last_stats = self._scene.render(W, H, self.sample_count, self.bounce_count,
                                                     env=self.environment_factor, seed=self.seed)
         return accum

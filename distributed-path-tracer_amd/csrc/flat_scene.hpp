@@ -135,6 +135,7 @@ struct FlatScene {
 	uint32_t kd_max_depth = 0;
 	bool any_texture = false;
 	bool any_alpha = false;              // some material can take the opacity / shadow-catcher pass-through branch
+	int32_t env_tex = -1;                // renderer::environment: index into `textures`, -1 = none
 
 	// LDS residency plan (plan_residency): the traversal arrays of the surfaces that fit one CU's LDS, indices local to them
 	std::vector<KdNode> res_nodes;

@@ -655,8 +655,15 @@ template <bool SUN, bool ALPHA, bool TEX, bool WORKER>
 DEV int shade_vertex(const DevScene& S, const ShadeRec* shade, const RenderParams& P, uint32_t pixel, uint32_t sample,
                      uint32_t& depth, uint32_t& pass, SceneHit h, V3& o, V3& d, V3& T, V3& L, ShadowReq& rq) {
 	rq.kind = REQ_NONE;
-	if (h.surface < 0) {
-		L = L + T * mk(P.env[0], P.env[1], P.env[2]);  // miss: environment_factor (renderer.cpp:443-451, shading_worker.cpp:28-41)
+	if (h.surface < 0) {   // miss: environment_factor, times the environment map when one is set (renderer.cpp:443-451, shading_worker.cpp:28-41)
+		V3 env = mk(P.env[0], P.env[1], P.env[2]);
+		if constexpr (TEX) {
+			if (S.env_tex >= 0) {   // core::equirectangular_proj (core/utils.hpp:22-27) of ray::get_dir()
+				const float4 e = tex_sample(S, S.env_tex, atan2f(d.z, d.x) * 0.1591F + 0.5F, asinf(d.y) * 0.3183F + 0.5F);
+				env = mk(e.x, e.y, e.z) * env;
+			}
+		}
+		L = L + T * env;
 		return V_DEAD;
 	}
 	const ShadeRec& R = shade[h.surface];

@@ -56,6 +56,7 @@ struct DevScene {
 	const uint8_t* texels;   // 8-bit texel bytes of all textures
 	const float* srgb_lut;   // [256] pow(b / 255, 2.2)
 	uint32_t any_texture;
+	int32_t env_tex;         // environment map (renderer::environment): texture index or -1
 	const uint32_t* model_space; // per model
 	int32_t n_models;
 	uint32_t n_surfaces, n_nodes, n_refs, n_tris;

@@ -151,7 +151,8 @@ int upload_scene(ptx_scene* sc) {
 	d.tex = (const TexRec*)sc->d_tex.p;
 	d.texels = (const uint8_t*)sc->d_texels.p;
 	d.srgb_lut = (const float*)sc->d_lut.p;
-	d.any_texture = h.any_texture ? 1u : 0u;
+	d.any_texture = (h.any_texture || h.env_tex >= 0) ? 1u : 0u;   // the TEX kernels also carry the environment lookup
+	d.env_tex = h.env_tex;
 	d.model_space = (const uint32_t*)sc->d_model_space.p;
 	d.n_spaces = (uint32_t)h.spaces.size();
 	d.n_surfaces = (uint32_t)h.surfaces.size();
@@ -281,6 +282,32 @@ int ptx_worker_event_load(ptx_ctx* ctx, const char* event_json_path, const char*
 		return set_err(PTX_ERR_PARSE, e.what());
 	}
 	return finish_scene(ctx, sc, scene);
+}
+
+int ptx_scene_set_environment(ptx_scene* sc, const char* png_path, int srgb) {
+	if (!sc) return set_err(PTX_ERR_INVALID, "ptx_scene_set_environment: scene is NULL");
+	FlatScene& h = sc->host;
+	try {
+		if (!png_path) h.env_tex = -1;
+		else {
+			uint32_t W = 0, H = 0, Cn = 0;
+			std::vector<uint8_t> px;
+			read_png(png_path, W, H, Cn, px);
+			h.textures.push_back(TexRec{W, H, Cn | (srgb ? 256u : 0u), (uint32_t)h.texels.size()});
+			h.texels.insert(h.texels.end(), px.begin(), px.end());
+			h.texture_paths.push_back(png_path);
+			h.env_tex = (int32_t)h.textures.size() - 1;
+		}
+	} catch (const Error& e) {
+		return set_err(e.code, e.msg);
+	} catch (const std::exception& e) {
+		return set_err(PTX_ERR_PARSE, e.what());
+	}
+	if (sc->ctx) {
+		std::lock_guard<std::mutex> lk(sc->ctx->mu);
+		return upload_scene(sc);   // textures changed: the whole (small) scene goes up again
+	}
+	return PTX_OK;
 }
 
 int ptx_scene_from_arrays(ptx_ctx* ctx, const ptx_scene_desc* d, ptx_scene** out) {

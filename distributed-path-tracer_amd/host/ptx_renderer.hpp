@@ -23,6 +23,7 @@ public:
 	uint32_t thread_count = 0;             // kept for source compatibility; the GPU grid replaces util::thread_pool
 	uint32_t sample_count = 10000;
 	uint8_t bounce_count = 4;
+	std::filesystem::path environment;     // PNG environment map (the reference holds a loaded image::texture, renderer.hpp:28); empty = none
 	float environment_factor[3] = {1, 1, 1};
 	bool transparent_background = false;   // debug path of the reference; not built: render() throws if set
 	uint32_t camera_index = 0;
@@ -42,6 +43,7 @@ public:
 		ptx_load_opts o{camera_index, sun_light_index};
 		ptx_scene_destroy(scene_);
 		scene_ = nullptr;
+		env_set_.clear();
 		check(ptx_scene_load_gltf(ctx_, path.string().c_str(), &o, &scene_));
 	}
 
@@ -49,6 +51,10 @@ public:
 	std::vector<float> render_accum(ptx_render_stats* stats = nullptr) const {
 		if (!scene_) throw std::runtime_error("render() before load_gltf()");
 		if (transparent_background || visualize_kd_tree_depth) throw std::runtime_error("transparent_background / visualize_kd_tree_depth are not built");
+		if (environment.string() != env_set_) {   // (re)load the map only when the field changed
+			check(ptx_scene_set_environment(scene_, environment.empty() ? nullptr : environment.string().c_str(), 1));
+			env_set_ = environment.string();
+		}
 		ptx_render_cfg c{};
 		c.W = resolution.x; c.H = resolution.y; c.spp = sample_count; c.bounces = bounce_count;
 		for (int k = 0; k < 3; k++) c.env[k] = environment_factor[k];
@@ -76,6 +82,7 @@ private:
 	}
 	ptx_ctx* ctx_ = nullptr;
 	ptx_scene* scene_ = nullptr;
+	mutable std::string env_set_;
 };
 
 }  // namespace core

@@ -105,6 +105,11 @@ typedef struct ptx_scene_desc {
 int ptx_scene_from_arrays(ptx_ctx* ctx, const ptx_scene_desc* desc, ptx_scene** out);
 void ptx_scene_destroy(ptx_scene* scene);
 
+/* renderer::environment (LIB/core/renderer.hpp:28: std::shared_ptr<image::texture>, sampled on a miss through
+ * core::equirectangular_proj, renderer.cpp:443-449 / shading_worker.cpp:28-35) = image_texture::load(png_path, srgb).
+ * The miss colour becomes texture(dir) * environment_factor. png_path == NULL removes the map. PNG only. */
+int ptx_scene_set_environment(ptx_scene* scene, const char* png_path, int srgb);
+
 typedef struct ptx_scene_info {
 	uint32_t n_models, n_surfaces, n_vertices, n_triangles;
 	uint32_t n_kd_nodes;      /* flattened 8-byte nodes (branches + leaves) */

@@ -23,7 +23,8 @@ ROOT = os.path.dirname(HERE)
 HARNESS = os.path.join(HERE, "_ref", "ref_harness")
 GOLD = os.path.join(ROOT, "tests", "golden")
 CORNELL = os.path.join(ROOT, "scenes", "cornell-box", "cornell.gltf")
-JACK = os.path.join(ROOT, "scenes", "jack-of-blades", "jack-of-blades.gltf")   # derived asset, see tools/make_jack_asset.py
+JACK = os.path.join(ROOT, "scenes", "jack-of-blades", "jack-of-blades.gltf")
+ENV_PNG = os.path.join(ROOT, "scenes", "jack-of-blades", "textures", "TORSO_baseColor.png")   # any PNG serves as an environment map   # derived asset, see tools/make_jack_asset.py
 
 
 def kd_stream(t, axis, split, left, right, first, count, refs):
@@ -118,6 +119,10 @@ def main():
             out["b4_cfg"] = np.array([W, H, spp, b], np.int32)
             np.savez_compressed(os.path.join(GOLD, "jack_mean.npz"), **out)
             print("jack_mean.npz written")
+        # environment map: equirectangular_proj + image_texture::sample + trace() on misses (renderer.cpp:443-449)
+        d = os.path.join(tmp, "env")
+        subprocess.check_call([HARNESS, "envmap", CORNELL, ENV_PNG, "1", d, "7", "512"], env=env)
+        pack(d, os.path.join(GOLD, "env_vectors.npz"))
         # a small deterministic PNG from renderer::render itself (single thread + fixed seed => reproducible)
         png = os.path.join(GOLD, "cornell_ref_64x64_16spp_4b.png")
         r = subprocess.check_output([HARNESS, "render", CORNELL, "64", "64", "16", "4", "1", png], env=env)

@@ -414,6 +414,8 @@ struct scene_t {
 	std::vector<model> models;      // in the order renderer::intersect visits them
 	std::vector<surface> surfaces;
 	std::vector<texture> textures;
+	texture env;               // renderer::environment (renderer.hpp:28): set by ora_scene_set_environment
+	bool has_env = false;
 	xform camera; float fov, tan_half_fov;
 	bool has_sun = false; m3 sun_basis; v3 sun_energy; float sun_radius;
 };
@@ -570,6 +572,19 @@ static f4 draws(const path_key& k, uint32_t depth, uint32_t pass, uint32_t block
 	return {u01(r.x), u01(r.y), u01(r.z), u01(r.w)};
 }
 
+// Miss colour: environment_factor, times the environment map when one is set (renderer.cpp:443-449, shading_worker.cpp:28-35):
+// core::equirectangular_proj (core/utils.hpp:22-27) + image_texture::sample.
+static v3 miss_colour(const scene_t& s, const float* env_factor, v3 dir, float* uv_out = nullptr, f4v* tex_out = nullptr) {
+	const v3 f = V(env_factor[0], env_factor[1], env_factor[2]);
+	if (!s.has_env) return f;
+	const float u = std::atan2(dir.z, dir.x) * 0.1591F + 0.5F;
+	const float v = std::asin(dir.y) * 0.3183F + 0.5F;
+	const f4v c = tex_sample(s.env, u, v);
+	if (uv_out) { uv_out[0] = u; uv_out[1] = v; }
+	if (tex_out) *tex_out = c;
+	return V(c.x, c.y, c.z) * f;
+}
+
 // ---------------------------------------------------------------- renderer::trace — renderer.cpp:437-643
 struct render_cfg {
 	uint32_t W, H, spp, bounces;
@@ -585,7 +600,7 @@ static v3 trace(trace_ctx& c, const path_key& key, uint32_t bounce, const ray& r
 	if (bounce == 0) return V(0, 0, 0);                      // fvec4::future = (0,0,0,1)
 	c.rays++;
 	scene_hit res = scene_intersect(*c.s, r, c.st);
-	if (!res.hit) return V(c.cfg->env[0], c.cfg->env[1], c.cfg->env[2]);   // renderer.cpp:443-451, no env texture
+	if (!res.hit) return miss_colour(*c.s, c.cfg->env, r.d);                 // renderer.cpp:443-451
 	const material& mt = c.s->surfaces[res.surface].mat;
 	const mat_sample ms = material_eval(mt, c.s->textures, res.u, res.v);   // renderer.cpp:458-462
 	v3 albedo = ms.albedo;
@@ -683,7 +698,7 @@ static v3 trace_worker(trace_ctx& c, const path_key& key, ray r) {
 		c.rays++;
 		scene_hit res = scene_intersect(*c.s, r, c.st);      // intersect_min_result == intersect on one worker
 		if (!res.hit) {                                      // shading_worker.cpp:28-41
-			color = color + scale * V(c.cfg->env[0], c.cfg->env[1], c.cfg->env[2]);
+			color = color + scale * miss_colour(*c.s, c.cfg->env, r.d);
 			break;
 		}
 		const material& mt = c.s->surfaces[res.surface].mat;
@@ -873,6 +888,24 @@ void ora_scene_set_textures(void* p, int n_images, const int* whc_srgb /*[n][4]*
 	}
 	for (size_t k = 0; k < s->surfaces.size(); k++)
 		for (int j = 0; j < 7; j++) s->surfaces[k].mat.tex[j] = surf_tex[7 * k + j];
+}
+// renderer::environment = image_texture (8-bit image, c channels, sRGB flag); data == nullptr removes it
+void ora_scene_set_environment(void* p, int w, int h, int c, int srgb, const uint8_t* data) {
+	scene_t* s = (scene_t*)p;
+	s->has_env = data != nullptr;
+	if (!data) return;
+	s->env.w = w; s->env.h = h; s->env.c = c; s->env.srgb = srgb != 0;
+	s->env.data.assign(data, data + (size_t)w * h * c);
+}
+// dirs[n][3] (unit) -> uv[n][2], rgba[n][4] (texture sample), colour[n][3] (x environment_factor)
+void ora_env_lookup(void* p, size_t n, const float* dirs, const float* env_factor, float* uv, float* rgba, float* colour) {
+	const scene_t& s = *(scene_t*)p;
+	for (size_t i = 0; i < n; i++) {
+		f4v t = {0, 0, 0, 0};
+		const v3 c = miss_colour(s, env_factor, V(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), uv + 2 * i, &t);
+		rgba[4 * i] = t.x; rgba[4 * i + 1] = t.y; rgba[4 * i + 2] = t.z; rgba[4 * i + 3] = t.w;
+		colour[3 * i] = c.x; colour[3 * i + 1] = c.y; colour[3 * i + 2] = c.z;
+	}
 }
 // in[n][2] uv -> out[n][12]: normal_ts(3) albedo(3) opacity roughness metallic emissive(3)  (material.cpp getters)
 void ora_material_eval(void* p, int surf, size_t n, const float* uv, float* out) {

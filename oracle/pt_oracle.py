@@ -345,6 +345,22 @@ class OracleScene:
             st = np.ascontiguousarray(a.surf_tex, np.int32)
             L.ora_scene_set_textures(self.h, len(self._img), _p(meta), ptrs, _p(st))
 
+    def set_environment(self, png_path, srgb=True):
+        """renderer::environment = image_texture::load(path, srgb) (renderer.hpp:28); None removes it."""
+        if png_path is None:
+            lib().ora_scene_set_environment(self.h, 0, 0, 0, 0, None)
+            return
+        self._env = np.ascontiguousarray(_decode_image(png_path), np.uint8)
+        h, w, c = self._env.shape
+        lib().ora_scene_set_environment(self.h, w, h, c, int(bool(srgb)), _p(self._env))
+
+    def env_lookup(self, dirs, env_factor=(1.0, 1.0, 1.0)):
+        d = np.ascontiguousarray(dirs, np.float32)
+        uv = np.zeros((len(d), 2), np.float32); rgba = np.zeros((len(d), 4), np.float32); col = np.zeros((len(d), 3), np.float32)
+        f = np.asarray(env_factor, np.float32)
+        lib().ora_env_lookup(self.h, C.c_size_t(len(d)), _p(d), _p(f), _p(uv), _p(rgba), _p(col))
+        return uv, rgba, col
+
     def __del__(self):
         try:
             lib().ora_scene_destroy(self.h)

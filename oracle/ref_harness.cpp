@@ -13,6 +13,7 @@
 //   scene   <gltf> <outdir>                     dump the loaded scene + KD trees as .npy
 //   vectors <gltf> <outdir> <seed> <n>          function-level known-answer vectors as .npy
 //   materials <gltf> <outdir> <seed> <n>        per surface: material::get_* (texture lookups) at n random uvs
+//   envmap <gltf> <png> <srgb> <outdir> <seed> <n>   environment-map lookups: equirectangular_proj + image_texture::sample + trace() on misses
 //   mean    <gltf> <out.npy> W H spp bounces threads   float32 mean image by calling trace()
 //   render  <gltf> W H spp bounces threads [out.png]   time renderer::render(), print JSON
 
@@ -23,6 +24,7 @@
 #include <path_tracer/core/utils.hpp>
 #include <path_tracer/image/image.hpp>
 #include <path_tracer/image/texture.hpp>
+#include <path_tracer/image/image_texture.hpp>
 #include <path_tracer/scene/camera.hpp>
 #include <path_tracer/scene/entity.hpp>
 #include <path_tracer/scene/model.hpp>
@@ -472,6 +474,33 @@ static int cmd_materials(const char* gltf, const std::string& dir, uint64_t seed
 	return 0;
 }
 
+// renderer::trace's miss branch with an environment map (renderer.cpp:443-449): core::equirectangular_proj
+// (core/utils.hpp:22-27) and image::image_texture::sample on a PNG loaded the way a caller of the library would
+// (image_texture::load(path, srgb)). Also one trace() per direction from far outside the scene, with the map set.
+static int cmd_envmap(const char* gltf, const char* png, int srgb, const std::string& dir, uint64_t seed, size_t n) {
+	core::renderer r;
+	load(r, gltf);
+	std::filesystem::create_directories(dir);
+	auto tex = image::image_texture::load(png, srgb != 0);
+	r.environment = tex;
+	r.environment_factor = fvec3(0.5F, 1.25F, 2.0F);
+	pcg32 g(seed);
+	std::vector<float> in, uvs, out, tr;
+	for (size_t i = 0; i < n; i++) {
+		fvec3 d(g.range(-1, 1), g.range(-1, 1), g.range(-1, 1));
+		if (i < 6) { d = fvec3(0); d[i / 2] = (i % 2) ? -1.0F : 1.0F; }      // the six axis directions (poles, seam)
+		d = normalize(d);
+		fvec2 uv = core::equirectangular_proj(d);
+		fvec4 c = tex->sample(uv);
+		push3(in, d); uvs.push_back(uv.x); uvs.push_back(uv.y);
+		out.push_back(c.x); out.push_back(c.y); out.push_back(c.z); out.push_back(c.w);
+		fvec4 t = r.trace(4, geometry::ray(fvec3(1000, 1000, 1000) + d, d));   // starts outside every box, points away: a miss
+		tr.push_back(t.x); tr.push_back(t.y); tr.push_back(t.z); tr.push_back(t.w);
+	}
+	save(dir, "env_in", in, {n, 3}); save(dir, "env_uv", uvs, {n, 2}); save(dir, "env_out", out, {n, 4}); save(dir, "env_trace", tr, {n, 4});
+	return 0;
+}
+
 // float32 mean image: same pixel loop as renderer::render (renderer.cpp:354-402) but keeping the
 // float running mean instead of the 8-bit image; rows are distributed statically over threads.
 static int cmd_mean(const char* gltf, const std::string& out, uint32_t W, uint32_t H, uint32_t spp, uint32_t bounces,
@@ -535,6 +564,7 @@ int main(int argc, char** argv) {
 		if (cmd == "scene" && argc == 4) return cmd_scene(argv[2], argv[3]);
 		if (cmd == "vectors" && argc == 6) return cmd_vectors(argv[2], argv[3], strtoull(argv[4], 0, 10), strtoull(argv[5], 0, 10));
 		if (cmd == "materials" && argc == 6) return cmd_materials(argv[2], argv[3], strtoull(argv[4], 0, 10), strtoull(argv[5], 0, 10));
+		if (cmd == "envmap" && argc == 8) return cmd_envmap(argv[2], argv[3], atoi(argv[4]), argv[5], strtoull(argv[6], 0, 10), strtoull(argv[7], 0, 10));
 		if (cmd == "mean" && argc == 9)
 			return cmd_mean(argv[2], argv[3], atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]));
 		if (cmd == "render" && argc >= 8)
@@ -543,6 +573,6 @@ int main(int argc, char** argv) {
 		fprintf(stderr, "ref_harness: %s\n", e.what());
 		return 2;
 	}
-	fprintf(stderr, "usage: ref_harness scene|vectors|materials|mean|render ... (see header comment)\n");
+	fprintf(stderr, "usage: ref_harness scene|vectors|materials|envmap|mean|render ... (see header comment)\n");
 	return 1;
 }

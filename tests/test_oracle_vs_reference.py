@@ -163,3 +163,25 @@ def test_jack_mean_image_statistics(jack_oracle, ora):
     noise = rl2(ra, rb)
     assert rl2(o, ra) < 1.25 * noise and rl2(o, rb) < 1.25 * noise, (rl2(o, ra), rl2(o, rb), noise)
     assert abs(o.mean() / ((ra.mean() + rb.mean()) / 2) - 1) < 0.02
+
+
+def test_environment_map_lookup_bit_exact(cornell_oracle, ora):
+    """renderer::trace's miss branch with renderer::environment set (renderer.cpp:443-449): core::equirectangular_proj +
+    image_texture::sample + environment_factor, against the compiled reference (512 directions incl. the poles and the seam)."""
+    import os
+    from conftest import GOLD, ROOT
+    g = np.load(os.path.join(GOLD, "env_vectors.npz"))
+    cornell_oracle.set_environment(os.path.join(ROOT, "scenes", "jack-of-blades", "textures", "TORSO_baseColor.png"), srgb=True)
+    try:
+        uv, rgba, col = cornell_oracle.env_lookup(g["env_in"], (0.5, 1.25, 2.0))
+        np.testing.assert_array_equal(uv.view(np.uint32), g["env_uv"].view(np.uint32))
+        np.testing.assert_array_equal(rgba.view(np.uint32), g["env_out"].view(np.uint32))
+        # trace() sees ray::get_dir(): the constructor normalises the direction once more (ray.cpp:6-8, vec3.inl:250-253: v * (1 / len))
+        d = g["env_in"].astype(np.float32)
+        ln = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], dtype=np.float32)
+        dn = d * (np.float32(1) / ln)[:, None]
+        _, _, col = cornell_oracle.env_lookup(dn, (0.5, 1.25, 2.0))
+        np.testing.assert_array_equal(col.view(np.uint32), g["env_trace"][:, :3].view(np.uint32))
+        assert (g["env_trace"][:, 3] == 1).all()
+    finally:
+        cornell_oracle.set_environment(None)
