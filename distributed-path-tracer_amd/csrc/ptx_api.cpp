@@ -6,6 +6,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdio>
 #include <cstdlib>
@@ -55,6 +56,7 @@ constexpr size_t kLdsBudget = 160 * 1024;  // per-CU LDS on gfx950; one workgrou
 }  // namespace
 
 struct ptx_ctx {
+	std::atomic<int> refs{1};   // the caller's handle + one per scene created on it: a scene may outlive ptx_ctx_destroy
 	int device = 0;
 	hipStream_t stream = nullptr;
 	int n_cu = 0;
@@ -172,6 +174,7 @@ int finish_scene(ptx_ctx* ctx, ptx_scene* sc, ptx_scene** out) {
 		std::lock_guard<std::mutex> lk(ctx->mu);
 		int rc = upload_scene(sc);
 		if (rc != PTX_OK) { delete sc; return rc; }
+		ctx->refs.fetch_add(1);
 	} else {
 		decide_mode(sc);
 	}
@@ -208,14 +211,17 @@ int ptx_ctx_create(int device, ptx_ctx** out) {
 	return PTX_OK;
 }
 
-void ptx_ctx_destroy(ptx_ctx* c) {
-	if (!c) return;
+static void ctx_release(ptx_ctx* c) {
+	if (c->refs.fetch_sub(1) != 1) return;   // scenes still alive: the last one frees the context
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
 	for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
 	c->queues.release(); c->spill.release(); c->sample_rad.release(); c->counters.release(); c->stage_a.release(); c->stage_b.release();
 	(void)hipStreamDestroy(c->stream);
 	delete c;
+}
+void ptx_ctx_destroy(ptx_ctx* c) {
+	if (c) ctx_release(c);
 }
 
 void* ptx_ctx_stream(ptx_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -363,8 +369,11 @@ void ptx_scene_destroy(ptx_scene* sc) {
 		(void)hipStreamSynchronize(sc->ctx->stream);
 		sc->d_models.release(); sc->d_surfaces.release(); sc->d_materials.release(); sc->d_nodes.release();
 		sc->d_refs.release(); sc->d_tris.release(); sc->d_vattr.release(); sc->d_isect.release(); sc->d_shade.release(); sc->d_tex.release(); sc->d_texels.release(); sc->d_lut.release(); sc->d_spaces.release(); sc->d_model_space.release();
+		sc->d_res_nodes.release(); sc->d_res_refs.release(); sc->d_res_tris.release();
 	}
+	ptx_ctx* c = sc->ctx;
 	delete sc;
+	if (c) ctx_release(c);
 }
 
 int ptx_scene_get_info(const ptx_scene* sc, ptx_scene_info* info) {

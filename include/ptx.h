@@ -43,6 +43,8 @@ const char* ptx_version(void);
 /* ---- context ------------------------------------------------------------------------------------
  * device >= 0: HIP device ordinal. Fails with PTX_ERR_NO_DEVICE when there is none. */
 int ptx_ctx_create(int device, ptx_ctx** out);
+/* Scenes created on the context keep it alive: it is freed together with the last of them, in whatever order the handles
+ * are destroyed. */
 void ptx_ctx_destroy(ptx_ctx* ctx);
 /* Stream the context launches on (hipStream_t as void*), for callers that time or order work. */
 void* ptx_ctx_stream(ptx_ctx* ctx);

@@ -152,3 +152,14 @@ def test_4k_frame_one_sample(scene, cornell_oracle, ora):
     assert (rel < 1e-3).mean() > 0.99
     q, _ = scene.render(W, H, 1, 4, tile=(W // 2, H // 2, W // 2, H // 2))
     np.testing.assert_array_equal(q, full[H // 2:, W // 2:])
+
+
+def test_context_destroyed_before_its_scene(ptx):
+    """Destruction order is free: a scene keeps its context alive (garbage collectors finalise cycles in arbitrary order)."""
+    from conftest import CORNELL
+    c = ptx.Context(0)
+    s = ptx.Scene.load_gltf(c, CORNELL)
+    c.close()                                   # ptx_ctx_destroy first
+    a, st = s.render(32, 18, 2, 3)              # the scene still renders on the context it holds
+    assert st["samples"] == 32 * 18 * 2 and np.isfinite(a).all()
+    s.close()                                   # the last reference frees the context
