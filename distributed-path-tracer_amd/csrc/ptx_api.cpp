@@ -8,7 +8,6 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
-#include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
