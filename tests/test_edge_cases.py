@@ -163,3 +163,21 @@ def test_context_destroyed_before_its_scene(ptx):
     a, st = s.render(32, 18, 2, 3)              # the scene still renders on the context it holds
     assert st["samples"] == 32 * 18 * 2 and np.isfinite(a).all()
     s.close()                                   # the last reference frees the context
+
+
+def test_non_finite_rays_and_scene_churn(scene, ptx, ctx):
+    """NaN / inf ray components are misses (every box comparison is false), never a hang; scenes can be created and destroyed
+    repeatedly on one context."""
+    from conftest import CORNELL
+    bad = np.array([[np.nan, 0, 0], [0, np.inf, 0], [0, 2, 11], [0, 2, 11], [0, 2, 11], [-np.inf, np.nan, 0]], np.float32)
+    dirs = np.array([[0, 0, -1], [0, 0, -1], [np.nan, 0, -1], [0, np.inf, 0], [0, 0, 0], [0, 0, -1]], np.float32)
+    h = scene.intersect(bad, dirs)
+    assert (h["surface"] == -1).all()
+    good = scene.intersect(np.array([[0, 2, 11]], np.float32), np.array([[0, 0, -1]], np.float32))
+    assert good["surface"][0] >= 0
+    ref, _ = scene.render(24, 16, 2, 3)
+    for _ in range(12):
+        s = ptx.Scene.load_gltf(ctx, CORNELL)
+        a, _ = s.render(24, 16, 2, 3)
+        np.testing.assert_array_equal(a, ref)
+        s.close()
