@@ -181,3 +181,33 @@ def test_non_finite_rays_and_scene_churn(scene, ptx, ctx):
         a, _ = s.render(24, 16, 2, 3)
         np.testing.assert_array_equal(a, ref)
         s.close()
+
+
+def test_concurrent_callers(scene, ptx):
+    """SURVEY §8b threading contract: ptx_render is safe to call from several host threads — on one context (serialised by the
+    context's lock) and on two contexts of the same device (own streams and workspaces) — and returns what a serial caller gets."""
+    import threading
+    from conftest import CORNELL
+    W, H, spp, b = 64, 48, 3, 4
+    full, _ = scene.render(W, H, spp, b)
+    tiles = [(0, 0, 32, 24), (32, 0, 32, 24), (0, 24, 32, 24), (32, 24, 32, 24)]
+    out, errs = {}, []
+
+    def work(sc, k, tile):
+        try:
+            for _ in range(5):
+                out[k], _ = sc.render(W, H, spp, b, tile=tile)
+        except Exception as e:        # pragma: no cover
+            errs.append(e)
+
+    c2 = ptx.Context(0)
+    s2 = ptx.Scene.load_gltf(c2, CORNELL)
+    th = [threading.Thread(target=work, args=(scene if k < 4 else s2, k, tiles[k % 4])) for k in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for k in range(8):
+        x0, y0, w, h = tiles[k % 4]
+        np.testing.assert_array_equal(out[k], full[y0:y0 + h, x0:x0 + w])
