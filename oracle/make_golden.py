@@ -73,12 +73,27 @@ def pack(src_dir, dst):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--no-mean", action="store_true")
+    ap.add_argument("--only-trace", action="store_true", help="regenerate trace_vectors.npz only")
     ap.add_argument("--n", type=int, default=1024)
     args = ap.parse_args()
     subprocess.check_call(["make", "-s", "-j8", "-C", HERE, "ref"])
     os.makedirs(GOLD, exist_ok=True)
     env = dict(os.environ, ORACLE_SEED="20261004")
     with tempfile.TemporaryDirectory() as tmp:
+        # ---- renderer::trace itself: n rays traced one after the other by ONE thread on ONE seeded mt19937 stream. Pins the
+        # integrator's COMPOSITION (draw order, lobe choice, sun block, BRDF / PDF combine, clamp, emissive x 10, opacity
+        # pass-through) bit for bit: the oracle replays the same stream (ora_trace_mt).
+        out = {}
+        for tag, gltf, seed, pcg, n, b in (("cornell", CORNELL, "424242", "9", 2000, 8), ("jack", JACK, "777", "10", 4000, 6)):
+            d = os.path.join(tmp, "trace_" + tag)
+            subprocess.check_call([HARNESS, "trace", gltf, d, pcg, str(n), str(b)], env=dict(env, ORACLE_SEED=seed))
+            out[tag + "_rays"] = np.load(os.path.join(d, "trace_rays.npy"))
+            out[tag + "_out"] = np.load(os.path.join(d, "trace_out.npy"))
+            out[tag + "_meta"] = np.load(os.path.join(d, "trace_meta.npy"))   # mt19937 seed, bounces, random_device calls (must be 1)
+        np.savez_compressed(os.path.join(GOLD, "trace_vectors.npz"), **out)
+        print(f"trace_vectors.npz written ({os.path.getsize(os.path.join(GOLD, 'trace_vectors.npz')) / 1024:.0f} KiB)")
+        if args.only_trace:
+            return
         d = os.path.join(tmp, "scene")
         subprocess.check_call([HARNESS, "scene", CORNELL, d], env=env)
         pack(d, os.path.join(GOLD, "cornell_scene.npz"))

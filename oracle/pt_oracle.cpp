@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <random>
 #include <string>
 #include <unordered_map>
 #include <thread>
@@ -594,7 +595,27 @@ struct render_cfg {
 	uint32_t sample0;           // first sample index
 	uint32_t integrator;        // 0 = renderer::trace (LIB), 1 = the HOST worker's stage pipeline (trace_worker below)
 };
-struct trace_ctx { const scene_t* s; const render_cfg* cfg; uint64_t rays = 0; trav_stats* st = nullptr; };
+// RNG of the reference, for pinning trace() bit-exactly against the compiled reference run single-threaded with a fixed seed
+// (oracle/ref_harness.cpp `trace`): core::rand() (core/utils.hpp:8-13) = one thread_local std::mt19937 seeded once from
+// std::random_device, drawn through std::uniform_real_distribution<float>(0, 1) — the same libstdc++ classes here, consumed in
+// the order trace() consumes them (renderer.cpp:466, 492, 500, 572). Where two rand() calls are arguments of ONE call
+// (renderer.cpp:500: rand_cone_vec(rand(), cos(rand() * r), ..); :572: fvec2(rand(), rand())) C++ leaves the order to the
+// compiler; `args_rtl` says which one the reference's g++ build took (settled empirically by tests/test_oracle_vs_reference.py:
+// only one setting reproduces the reference bit for bit).
+struct mt_stream {
+	std::mt19937 rng;
+	std::uniform_real_distribution<float> dist{0, 1};
+	bool args_rtl = true;
+	uint64_t n_draws = 0;
+	explicit mt_stream(uint32_t seed, bool rtl) : rng(seed), args_rtl(rtl) {}
+	float next() { n_draws++; return dist(rng); }
+	// the two draws of one call's argument list: first = the value of the FIRST argument, second = of the second
+	void pair(float& first, float& second) {
+		if (args_rtl) { second = next(); first = next(); }
+		else { first = next(); second = next(); }
+	}
+};
+struct trace_ctx { const scene_t* s; const render_cfg* cfg; uint64_t rays = 0; trav_stats* st = nullptr; mt_stream* mt = nullptr; };
 
 static v3 trace(trace_ctx& c, const path_key& key, uint32_t bounce, const ray& r, uint32_t pass) {
 	if (bounce == 0) return V(0, 0, 0);                      // fvec4::future = (0,0,0,1)
@@ -608,9 +629,11 @@ static v3 trace(trace_ctx& c, const path_key& key, uint32_t bounce, const ray& r
 	v3 emissive = ms.emissive * 10;                          // renderer.cpp:462
 	float ior = mt.ior;
 	uint32_t depth = c.cfg->bounces - bounce;
-	f4 rnd = draws(key, depth, pass, BLOCK_SURFACE);         // x: opacity, y: lobe, z,w: BSDF sample
+	// counter-based stream (product and oracle share it): x: opacity, y: lobe, z,w: BSDF sample. With c.mt set the draws are
+	// taken from the reference's sequential stream instead, at the points where trace() calls rand().
+	f4 rnd = c.mt ? f4{0, 0, 0, 0} : draws(key, depth, pass, BLOCK_SURFACE);
 
-	if (!is_approx(opacity, 1) && rnd.x > opacity)           // renderer.cpp:466-472
+	if (!is_approx(opacity, 1) && (c.mt ? c.mt->next() : rnd.x) > opacity)   // renderer.cpp:466-472 (rand() only when opacity != 1)
 		return trace(c, key, bounce, make_ray(res.pos + r.d * EPS, r.d), pass + 1);
 
 	v3 normal = shading_normal(res, ms.normal_ts);
@@ -620,11 +643,12 @@ static v3 trace(trace_ctx& c, const path_key& key, uint32_t bounce, const ray& r
 	roughness = fmax2(roughness, 0.05F);
 	float specular_probability = fresnel(outcoming, reflect(-outcoming, normal), ior);
 	specular_probability = fmax2(specular_probability, metallic);
-	bool specular_sample = rnd.y < specular_probability;
+	bool specular_sample = (c.mt ? c.mt->next() : rnd.y) < specular_probability;   // renderer.cpp:492
 
 	v3 direct_out = V(0, 0, 0);
 	if (c.s->has_sun) {                                      // renderer.cpp:498-564
-		f4 sr = draws(key, depth, pass, BLOCK_SUN);            // x: azimuth draw, y: cone-angle draw
+		f4 sr = c.mt ? f4{0, 0, 0, 0} : draws(key, depth, pass, BLOCK_SUN);   // x: azimuth draw, y: cone-angle draw
+		if (c.mt) c.mt->pair(sr.x, sr.y);                      // renderer.cpp:500: rand_cone_vec(rand(), cos(rand() * radius), ..)
 		v3 direct_incoming = c.s->sun_basis * V(0, 0, 1);
 		direct_incoming = rand_cone_vec(sr.x, std::cos(sr.y * c.s->sun_radius), direct_incoming);
 		if (dot(normal, direct_incoming) > 0) {
@@ -656,6 +680,7 @@ static v3 trace(trace_ctx& c, const path_key& key, uint32_t bounce, const ray& r
 	}
 
 	v3 indirect_out = V(0, 0, 0);
+	if (c.mt) c.mt->pair(rnd.z, rnd.w);                      // renderer.cpp:572: fvec2 rand(core::rand(), core::rand())
 	v3 indirect_incoming = specular_sample ? importance_specular(rnd.z, rnd.w, normal, outcoming, roughness)
 	                                       : importance_diffuse(rnd.z, rnd.w, normal);
 	if (dot(normal, indirect_incoming) > 0) {                // renderer.cpp:578-621
@@ -1119,6 +1144,29 @@ void ora_render(void* p, const render_cfg* cfg, float* mean_rgba, int threads, u
 			stats[4] += tst[t].leaves; stats[5] += tst[t].tris; stats[6] += tst[t].pushes;
 		}
 	}
+}
+
+// renderer::trace(bounces, ray) for n rays IN SEQUENCE on ONE mt19937 stream seeded with `seed` — what the compiled reference
+// computes single-threaded with the seed shim of oracle/ref_harness.cpp (`trace` sub-command). out[n][4] = rgb + alpha (alpha is 1
+// on every return of trace() with transparent_background = false, renderer.cpp:438-451,643). n_draws (optional) = rand() calls.
+void ora_trace_mt(void* p, size_t n, const float* rays /*[n][6]*/, uint32_t bounces, const float* env3, uint32_t seed, int args_rtl,
+                  float* out /*[n][4]*/, uint64_t* n_draws) {
+	const scene_t& s = *(scene_t*)p;
+	render_cfg cfg{};
+	cfg.bounces = bounces;
+	cfg.env[0] = env3[0]; cfg.env[1] = env3[1]; cfg.env[2] = env3[2];
+	mt_stream mt(seed, args_rtl != 0);
+	trace_ctx c{&s, &cfg};
+	c.mt = &mt;
+	const path_key unused{0, 0, 0, 0};
+	for (size_t i = 0; i < n; i++) {
+		const float* r = rays + 6 * i;
+		// the direction is used as given (the harness stores ray::get_dir(), already normalised by the ray's constructor; normalising
+		// again is not idempotent in float and would move ~1 % of the rays by an ulp)
+		const v3 d = trace(c, unused, bounces, ray{V(r[0], r[1], r[2]), V(r[3], r[4], r[5])}, 0);
+		out[4 * i] = d.x; out[4 * i + 1] = d.y; out[4 * i + 2] = d.z; out[4 * i + 3] = 1.0f;
+	}
+	if (n_draws) *n_draws = mt.n_draws;
 }
 
 // Per-sample radiance (no averaging): out[h][w][spp][3]. Used to compare individual paths with the GPU.

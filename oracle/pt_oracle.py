@@ -429,6 +429,17 @@ class OracleScene:
         lib().ora_render(self.h, C.byref(cfg), _p(img), C.c_int(threads), _p(st), C.c_int(1 if stats else 0))
         return img, st
 
+    def trace_mt(self, rays, bounces, seed, env=(1.0, 1.0, 1.0), args_rtl=True):
+        """renderer::trace(bounces, ray) for every ray in sequence on one std::mt19937(seed) stream, drawn in the reference's
+        order (what oracle/_ref/ref_harness `trace` computes). -> (rgba [n,4] float32, number of rand() calls)"""
+        rays = np.ascontiguousarray(rays, np.float32)
+        out = np.zeros((len(rays), 4), np.float32)
+        nd = C.c_uint64(0)
+        e = np.asarray(env, np.float32)
+        lib().ora_trace_mt(self.h, C.c_size_t(len(rays)), _p(rays), C.c_uint32(bounces), _p(e), C.c_uint32(seed), C.c_int(1 if args_rtl else 0),
+                           _p(out), C.byref(nd))
+        return out, int(nd.value)
+
     def render_samples(self, cfg, threads=0):
         out = np.zeros((cfg.h, cfg.w, cfg.spp, 3), np.float32)
         lib().ora_render_samples(self.h, C.byref(cfg), _p(out), C.c_int(threads))

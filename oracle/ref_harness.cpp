@@ -14,6 +14,8 @@
 //   vectors <gltf> <outdir> <seed> <n>          function-level known-answer vectors as .npy
 //   materials <gltf> <outdir> <seed> <n>        per surface: material::get_* (texture lookups) at n random uvs
 //   envmap <gltf> <png> <srgb> <outdir> <seed> <n>   environment-map lookups: equirectangular_proj + image_texture::sample + trace() on misses
+//   trace   <gltf> <outdir> <seed> <n> <bounces>      trace() of n rays in sequence, ONE thread, ONE seeded mt19937 stream: pins the
+//                                                     integrator's composition bit for bit (oracle side: ora_trace_mt)
 //   mean    <gltf> <out.npy> W H spp bounces threads   float32 mean image by calling trace()
 //   render  <gltf> W H spp bounces threads [out.png]   time renderer::render(), print JSON
 
@@ -501,6 +503,49 @@ static int cmd_envmap(const char* gltf, const char* png, int srgb, const std::st
 	return 0;
 }
 
+// renderer::trace (renderer.cpp:437-643) on n rays, one after the other, on the calling thread only. core::rand() is a `static`
+// function of core/utils.hpp, so renderer.cpp's copy owns its own thread_local mt19937, seeded at its first call from
+// std::random_device — the shim above, which has not been called before (this harness draws its inputs from pcg32): the stream is
+// std::mt19937(ORACLE_SEED). Half of the rays are camera rays (random NDC), half start at the camera and aim at a random point of
+// the scene's bounds (so that assets most camera rays miss are still exercised); every ray is traced with the full bounce budget.
+static int cmd_trace(const char* gltf, const std::string& dir, uint64_t seed, size_t n, uint32_t bounces) {
+	core::renderer r;
+	load(r, gltf);
+	std::filesystem::create_directories(dir);
+	r.bounce_count = (uint8_t)bounces;
+	auto models = visit_order(r);
+	pcg32 g(seed);
+	fvec3 wmin(1e30f), wmax(-1e30f);
+	for (auto& m : models) {
+		const scene::transform& t = m.ent->get_global_transform();
+		for (int k = 0; k < 8; k++) {
+			fvec3 c((k & 1) ? m.model->aabb.max.x : m.model->aabb.min.x, (k & 2) ? m.model->aabb.max.y : m.model->aabb.min.y,
+			        (k & 4) ? m.model->aabb.max.z : m.model->aabb.min.z);
+			fvec3 w = t * c;
+			wmin = math::min(wmin, w); wmax = math::max(wmax, w);
+		}
+	}
+	auto cam = r.camera->get_component<scene::camera>();
+	const fvec3 eye = r.camera->get_global_transform().origin;
+	std::vector<float> in, out;
+	if (g_seed_calls.load() != 0) { fprintf(stderr, "trace: random_device was already used\n"); return 3; }
+	const size_t skip = getenv("ORACLE_TRACE_SKIP") ? strtoull(getenv("ORACLE_TRACE_SKIP"), nullptr, 10) : 0;
+	for (size_t i = 0; i < n; i++) {
+		geometry::ray ray = (i & 1) ? geometry::ray(eye, normalize(wmin + (wmax - wmin) * g.vec(0.05f, 0.95f) - eye))
+		                            : cam->get_ray(fvec2(g.range(-1, 1), g.range(-1, 1)), 16.f / 9.f);
+		if (i < skip) continue;   // ORACLE_TRACE_SKIP: inputs are still drawn, so ray i is the same ray whatever is skipped
+		fvec4 c = r.trace((uint8_t)bounces, ray);
+		push3(in, ray.origin); push3(in, ray.get_dir());
+		out.push_back(c.x); out.push_back(c.y); out.push_back(c.z); out.push_back(c.w);
+	}
+	if (g_seed_calls.load() > 1) { fprintf(stderr, "trace: more than one mt19937 stream was seeded (%u)\n", g_seed_calls.load()); return 3; }
+	save(dir, "trace_rays", in, {in.size() / 6, 6}); save(dir, "trace_out", out, {out.size() / 4, 4});
+	const char* sd = getenv("ORACLE_SEED");
+	std::vector<uint32_t> meta = {(uint32_t)(sd ? strtoul(sd, nullptr, 10) : 12345u), bounces, (uint32_t)g_seed_calls.load()};
+	save(dir, "trace_meta", meta);
+	return 0;
+}
+
 // float32 mean image: same pixel loop as renderer::render (renderer.cpp:354-402) but keeping the
 // float running mean instead of the 8-bit image; rows are distributed statically over threads.
 static int cmd_mean(const char* gltf, const std::string& out, uint32_t W, uint32_t H, uint32_t spp, uint32_t bounces,
@@ -565,6 +610,7 @@ int main(int argc, char** argv) {
 		if (cmd == "vectors" && argc == 6) return cmd_vectors(argv[2], argv[3], strtoull(argv[4], 0, 10), strtoull(argv[5], 0, 10));
 		if (cmd == "materials" && argc == 6) return cmd_materials(argv[2], argv[3], strtoull(argv[4], 0, 10), strtoull(argv[5], 0, 10));
 		if (cmd == "envmap" && argc == 8) return cmd_envmap(argv[2], argv[3], atoi(argv[4]), argv[5], strtoull(argv[6], 0, 10), strtoull(argv[7], 0, 10));
+		if (cmd == "trace" && argc == 7) return cmd_trace(argv[2], argv[3], strtoull(argv[4], 0, 10), strtoull(argv[5], 0, 10), atoi(argv[6]));
 		if (cmd == "mean" && argc == 9)
 			return cmd_mean(argv[2], argv[3], atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]));
 		if (cmd == "render" && argc >= 8)
@@ -573,6 +619,6 @@ int main(int argc, char** argv) {
 		fprintf(stderr, "ref_harness: %s\n", e.what());
 		return 2;
 	}
-	fprintf(stderr, "usage: ref_harness scene|vectors|materials|envmap|mean|render ... (see header comment)\n");
+	fprintf(stderr, "usage: ref_harness scene|vectors|materials|envmap|trace|mean|render ... (see header comment)\n");
 	return 1;
 }
