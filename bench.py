@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the hot path (BASELINE.json config 2).
+"""bench.py — headline benchmark of the hot path (BASELINE.json configs[1]).
 
-A "step" = one pass of the integrator over one batch of synthetic input: the Cornell-box scene
-(scenes/cornell-box, the reference's own asset) at 1920x1080, 256 spp, 8 bounces on each GPU,
-entirely through the C ABI (ptx_render). Inputs (scene) are resident in HBM before the timed region.
-With N > 1 ranks (one process per GPU, torch.distributed / RCCL) every rank renders its own 256-sample
-range of the same frame (weak scaling: the frame gets N*256 spp) and the float32 accumulation buffers
-are sum-reduced to rank 0 over xGMI inside the timed region — the path's only exchange step.
+A "step" = one pass of the integrator over one batch of synthetic input: ONE frame of the Cornell-box scene
+(scenes/cornell-box, the reference's own asset) at 1920x1080, 256 spp, 8 bounces, entirely through the C ABI (ptx_render).
+The scene is resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0 (see the bench contract): value = whole-job Msamples/s; plus
-  roofline    — dominant kernel (k_render_pass): algorithmic bytes per launch / HIP-event kernel time
-  cpu_baseline — the UNMODIFIED reference renderer (oracle/_ref/ref_harness) timed on this box's host cores
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N = 1: one process, one GPU. N > 1: one process per GPU over RCCL (torch.distributed "nccl"); when this script is started from a
+plain shell (no WORLD_SIZE) with --gpus N > 1 it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+CHILD process (before anything here touches a GPU), relays rank 0's JSON line and exits with the child's code. Under
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE set, as the driver launches it) it is one rank of the job.
+Default for N > 1 is STRONG scaling: the same 256-spp frame, each rank tracing its contiguous share of the sample indices of every
+pixel (--shard tiles: interleaved 64x64 image tiles instead), then ONE RCCL sum-reduce of the float32 accumulation buffer onto
+rank 0 inside the timed region. --weak: every rank traces 256 spp of its own (the frame gets N*256).
+
+Prints ONE JSON line on rank 0 (bench contract): value = whole-job Msamples/s; plus
+  roofline     — dominant kernel (k_render_pass), bound by the resource that limits it (VALU issue), with the HBM view beside it
+  psnr_db      — GPU vs CPU oracle on a fixed 1080p tile at equal spp and RNG keys (outside the timed region)
+  cpu_baseline — the UNMODIFIED reference renderer (oracle/_ref/ref_harness) timed on this box's host cores, best of 3
 """
 import argparse
+import glob
+import hashlib
 import importlib
 import json
 import os
@@ -23,63 +33,94 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 CORNELL = os.path.join(ROOT, "scenes", "cornell-box", "cornell.gltf")
+KERNEL_SRC = os.path.join(ROOT, "distributed-path-tracer_amd", "csrc", "kernels.hip")
 
 W, H, SPP, BOUNCES = 1920, 1080, 256, 8
-# algorithmic bytes per ray on the reference-topology Cornell trees
-#   188 (ray/hit/path-state streams) + 8*3.44 (KD nodes) + 40*11.82 (leaf triangles) + 192 (hit attributes)
-B_RAY_CORNELL = 188 + 8 * 3.44 + 40 * 11.82 + 192
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
+# /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0          # HBM3E spec peak
+N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs
+# SURVEY.md §8(d), HBM part only: ray / hit / path-state streams 188 B per ray + 192 B of hit attributes per hit; the KD nodes and
+# triangle records (8*3.44 + 40*11.82 = 500 B per ray on the Cornell trees) are served by LDS in this kernel and never reach HBM
+B_STREAM, B_ATTR = 188.0, 192.0
+B_RAY_CORNELL_ALL = 188 + 8 * 3.44 + 40 * 11.82 + 192   # the full §8(d) figure (880.3), reported for reference
 
 
-def measured_traffic(rays_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed PMC profile (FETCH_SIZE / WRITE_SIZE are collected
-    in separate rocprofv3 --pmc passes — tools/pmc_passes.sh — and cannot be read live here): the measured bytes per ray
-    times the rays of this run's launches (a launch covers more samples than the profiled one; bytes per ray do not
-    depend on that). None if no profile."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")))
+def kernel_profile():
+    """Per-ray hardware counts of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/round*_kernel_pmc.json:
+    they need separate profiler passes — tools/pmc_passes.sh — and cannot be collected inside this process). Deterministic per
+    (binary, workload): instruction and byte counts per ray do not depend on the run; only the TIME is measured live here.
+    `stale` says whether kernels.hip changed since the profile was taken."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_kernel_pmc.json")))
     if not files:
         return None
     with open(files[-1]) as fh:
-        per_ray = json.load(fh).get("traffic_bytes_per_ray")
-    return None if per_ray is None else round(per_ray * rays_per_launch)
-
-
-def measured_valu():
-    """VALU issue-slot occupancy of the dominant kernel from the committed PMC profile (the resource that actually binds it:
-    DESIGN.md "Roofline accounting"). None if no profile."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_valu.json")))
-    if not files:
-        return None
-    with open(files[-1]) as fh:
-        v = json.load(fh)
-    return {"valu_issue_frac": v.get("valu_issue_frac"), "lane_utilisation": v.get("lane_utilisation")}
+        p = json.load(fh)
+    p["file"] = os.path.relpath(files[-1], ROOT)
+    with open(KERNEL_SRC, "rb") as fh:
+        p["stale"] = hashlib.sha256(fh.read()).hexdigest()[:16] != p.get("kernels_hip_sha256_16")
+    return p
 
 
 def cpu_baseline():
-    """Time the reference's own renderer::render on the host cores: 1080p, 8 bounces, 1 spp (~10 s)."""
+    """Time the reference's own renderer::render on the host cores: 1080p, 8 bounces, 1 spp (6-9 s each), best of 3."""
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     if os.path.exists(harness):
-        # the reference's thread pool stops scaling early (allocator / refcount contention, SURVEY §6): on the
-        # GPU box (256 hardware threads, 16-core share per GPU) 16 threads is its best setting (8: 0.23,
-        # 16: 0.65, 32: 0.20, 64: 0.13, 128: 0.11, 256: 0.08 Msamples/s), so that is what is timed
+        # the reference's thread pool stops scaling early (allocator / refcount contention, SURVEY §6): on the GPU box (16-core share
+        # per GPU) 16 threads is its best setting (8: 0.23, 16: 0.65, 32: 0.20, 64: 0.13 Msamples/s at 960x540), so that is what is timed
         threads = str(min(16, os.cpu_count() or 1))
-        out = subprocess.run([harness, "render", CORNELL, str(W), str(H), "1", str(BOUNCES), threads],
-                             capture_output=True, text=True, timeout=600)
-        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-        r = json.loads(line)
-        return {"value": round(r["msamples_per_s"], 4), "unit": "Msamples/s", "cores": r["threads"], "kind": "reference",
-                "sample": f"Cornell {W}x{H}, 1 spp, {BOUNCES} bounces (2.07 M camera paths), renderer::render of the "
-                          f"unmodified reference, {r['seconds']:.1f} s"}
+        runs = []
+        for _ in range(3):
+            out = subprocess.run([harness, "render", CORNELL, str(W), str(H), "1", str(BOUNCES), threads],
+                                 capture_output=True, text=True, timeout=600)
+            runs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]))
+        best = max(runs, key=lambda r: r["msamples_per_s"])
+        return {"value": round(best["msamples_per_s"], 4), "unit": "Msamples/s", "cores": best["threads"], "kind": "reference",
+                "runs": [round(r["msamples_per_s"], 4) for r in runs],
+                "sample": f"Cornell {W}x{H}, 1 spp, {BOUNCES} bounces (2.07 M camera paths), renderer::render of the unmodified "
+                          f"reference, best of 3 runs ({', '.join('%.1f s' % r['seconds'] for r in runs)})"}
     # the compiled reference is absent: time the oracle (my CPU restatement) instead
     from oracle import pt_oracle as ora
     sc = ora.OracleScene(ora.load_gltf(CORNELL))
     t = time.time()
-    _, st = sc.render(ora.make_cfg(W, H, 1, BOUNCES), threads=0)
+    sc.render(ora.make_cfg(W, H, 1, BOUNCES), threads=0)
     dt = time.time() - t
     return {"value": round(W * H / dt / 1e6, 4), "unit": "Msamples/s", "cores": os.cpu_count(), "kind": "port",
             "sample": f"Cornell {W}x{H}, 1 spp, {BOUNCES} bounces, oracle restatement, {dt:.1f} s"}
+
+
+def psnr_vs_oracle(ptx, scene, ctx):
+    """PSNR (8-bit, after tonemap + sRGB: the reference's output space) of the GPU path against the CPU oracle on a fixed tile of the
+    benchmark frame, equal spp, same RNG keys. The oracle is the checker here, never the thing measured."""
+    from oracle import pt_oracle as ora
+    tile, spp = (832, 420, 192, 108), 8
+    mean, _ = ora.OracleScene(ora.load_gltf(CORNELL)).render(ora.make_cfg(W, H, spp, BOUNCES, tile=tile), threads=0)
+    accum, _ = scene.render(W, H, spp, BOUNCES, tile=tile)
+    return {"psnr_db": round(min(ora.psnr8(ctx.tonemap_encode(accum, tile[2], tile[3], spp), ora.tonemap_write(mean)), 99.0), 2),
+            "psnr_sample": f"tile {tile[2]}x{tile[3]} at ({tile[0]},{tile[1]}) of the {W}x{H} frame, {spp} spp, {BOUNCES} bounces, "
+                           f"8-bit RGB after tonemap, GPU vs oracle/pt_oracle.cpp"}
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 from a plain shell: run the N ranks as a fresh child job; this process never touches a GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in r.stdout.splitlines():
+        if l not in lines:
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    elif r.returncode == 0:
+        print("bench.py: the ranks produced no result line", file=sys.stderr)
+        return 1
+    return r.returncode
 
 
 def main():
@@ -87,22 +128,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel per GPU per step (default: the BASELINE config)")
+    ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel of the frame (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--shard", choices=("samples", "tiles"), default="samples",
-                    help="samples: every rank traces --spp samples of every pixel (weak scaling, the default); "
-                         "tiles: ONE --spp frame split into row bands across ranks (strong scaling)")
+                    help="how ONE frame is split over N ranks: contiguous shares of the sample indices (default) or interleaved 64x64 tiles")
+    ap.add_argument("--weak", action="store_true", help="weak scaling instead: every rank traces --spp samples of its own")
     args = ap.parse_args()
 
-    import numpy as np
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: no GPU for local rank {local_rank} (this benchmark has no CPU path)")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # BENCH_FORCE_DIST: exercise the RCCL path with one rank
     if use_dist:
@@ -114,15 +160,18 @@ def main():
     scene = ptx.Scene.load_gltf(ctx, CORNELL)      # scene is uploaded to HBM here, outside the timed region
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     spp = args.spp
+    mode = "weak" if args.weak else args.shard
 
     def step(collect):
         accum.zero_()
         torch.cuda.synchronize()
-        # this rank's sample range -> ptx_render (syncs the ctx stream) -> RCCL sum-reduce of the framebuffer onto rank 0
-        if args.shard == "tiles":
+        # this rank's share -> ptx_render -> (N > 1) RCCL sum-reduce of the framebuffer onto rank 0
+        if mode == "weak":
+            st = mg.render_sharded(scene, W, H, spp, BOUNCES, accum, rank, world, want_stats=True)
+        elif mode == "tiles":
             st = mg.render_tiles(scene, W, H, spp, BOUNCES, accum, rank, world, want_stats=True)
         else:
-            st = mg.render_sharded(scene, W, H, spp, BOUNCES, accum, rank, world, want_stats=True)
+            st = mg.render_samples(scene, W, H, spp, BOUNCES, accum, rank, world, want_stats=True)
         if collect is not None:
             collect.append(st)
 
@@ -140,47 +189,79 @@ def main():
         step(stats)
     barrier()
     dt = time.perf_counter() - t0
+    my_rays = float(sum(s["rays"] for s in stats))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        r = torch.tensor([sum(s["rays"] for s in stats)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        r = torch.tensor([my_rays], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         total_rays = float(r.item())
     else:
-        total_rays = float(sum(s["rays"] for s in stats))
+        total_rays = my_rays
 
     if rank == 0:
-        weak = args.shard == "samples"
-        samples = float(W) * H * spp * (world if weak else 1) * args.steps
+        spp_total = spp * world if mode == "weak" else spp
+        samples = float(W) * H * spp_total * args.steps
         launches = sum(s["passes"] for s in stats)
-        kernel_ms = sum(s["kernel_ms"] for s in stats) / max(launches, 1)     # average launch of k_render_pass (HIP events)
-        rays_per_launch = sum(s["rays"] for s in stats) / max(launches, 1)
-        achieved = rays_per_launch * B_RAY_CORNELL / (kernel_ms * 1e-3) / 1e9  # GB/s, algorithmic
+        kernel_ms = sum(s["kernel_ms"] for s in stats) / max(launches, 1)     # average launch of k_render_pass on rank 0 (HIP events on the ctx stream)
+        rays_per_launch = my_rays / max(launches, 1)
+        hit_frac = 0.866                                                      # fraction of Cornell rays that hit a surface (oracle counters)
+        prof = kernel_profile()
+        # --- binding resource: VALU issue. Peak = one wave64 VALU instruction per SIMD every 2 cycles (measured: v_add_f32 2.00 cycles per
+        # instruction per SIMD at >= 2 waves per SIMD, profiles/round2_valu_issue.txt) at the clock the kernel held; achieved = the kernel's
+        # wave64 VALU instructions per second (count per ray from the PMC profile x this run's rays / this run's kernel time).
+        roof = {"bound": "valu", "kernel": "k_render_pass<LDS>", "avg_launch_ms": round(kernel_ms, 4), "launches": launches,
+                "rays_per_launch": round(rays_per_launch)}
+        hbm_alg = rays_per_launch * (B_STREAM + hit_frac * B_ATTR)
+        hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "algorithmic_bytes_per_ray": round(B_STREAM + hit_frac * B_ATTR, 1),
+               "algorithmic_note": "SURVEY §8(d) without the geometry term: streams 188 B + 192 B x hit fraction; KD nodes / triangle records "
+                                   f"(500 B per ray of the {B_RAY_CORNELL_ALL:.0f} B figure) are LDS-resident and never reach HBM",
+               "achieved": round(hbm_alg / (kernel_ms * 1e-3) / 1e9, 1)}
+        hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBS, 4)
+        if prof:
+            clock_ghz = prof["shader_clock_ghz"]
+            valu_per_ray = prof["valu_insts_per_ray"]
+            achieved = valu_per_ray * rays_per_launch / (kernel_ms * 1e-3) / 1e9          # G wave-instructions / s
+            peak = N_SIMD * clock_ghz / 2.0
+            traffic = prof["hbm_bytes_per_ray"] * rays_per_launch
+            roof.update({"achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "G wave64-VALU-instr/s", "frac": round(achieved / peak, 4),
+                         "peak_note": f"{N_SIMD} SIMDs x {clock_ghz} GHz / 2 cycles per instruction",
+                         "busy_frac_mix_weighted": prof.get("valu_busy_frac_mix_weighted"),
+                         "lane_utilisation": prof.get("lane_utilisation"),
+                         "traffic": round(traffic), "traffic_source": prof["file"], "counters_stale": prof["stale"]})
+            hbm.update({"traffic_bytes_per_launch": round(traffic), "traffic_gbs": round(traffic / (kernel_ms * 1e-3) / 1e9, 1),
+                        "traffic_frac_of_peak": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        else:
+            roof.update({"achieved": None, "peak": None, "unit": "G wave64-VALU-instr/s", "frac": None, "traffic": None,
+                         "traffic_source": None})
+        roof["hbm"] = hbm
+        what = {"weak": f"{spp} spp per GPU (weak scaling: {spp_total} spp per frame)",
+                "samples": f"{spp} spp per frame" + (f", sample indices split over {world} GPUs (strong scaling)" if world > 1 else ""),
+                "tiles": f"{spp} spp per frame" + (f", interleaved 64x64 tiles over {world} GPUs (strong scaling)" if world > 1 else "")}[mode]
         out = {
-            "metric": "Msamples/sec, Cornell box 1920x1080, 256 spp, 8 bounces (camera paths traced per second)",
+            "metric": f"Msamples/sec, Cornell box {W}x{H}, {what}, {BOUNCES} bounces (camera paths traced per second)",
             "value": round(samples / dt / 1e6, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Cornell box (scenes/cornell-box/cornell.gltf) {W}x{H}, {spp} spp per {'GPU' if weak else 'frame'}, {BOUNCES} bounces, "
-                                   f"1xMI355X per rank (BASELINE.json configs[1])",
-                       "spp_total": spp * world if weak else spp,
-                       "sharding": "none" if world == 1 else ("sample ranges per rank" if weak else "row bands per rank") + " + RCCL sum-reduce of the accumulation buffer"},
+            "higher_is_better": True, "scaling": "weak" if mode == "weak" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Cornell box (scenes/cornell-box/cornell.gltf) {W}x{H}, {spp_total} spp per frame, {BOUNCES} bounces "
+                                   f"(BASELINE.json configs[1]) on {world} x MI355X",
+                       "spp_total": spp_total,
+                       "sharding": "none" if world == 1 else
+                                   {"weak": "a sample range of its own per rank", "samples": "contiguous shares of the frame's sample indices per rank",
+                                    "tiles": "interleaved 64x64 tiles per rank"}[mode] + " + ONE RCCL sum-reduce of the accumulation buffer"},
             "mrays_per_s": round(total_rays / dt / 1e6, 2),
             "rays_per_sample": round(total_rays / samples, 4),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(rays_per_launch),
-                         "algorithmic_bytes_per_launch": round(rays_per_launch * B_RAY_CORNELL),
-                         "kernel": "k_render_pass<LDS>", "avg_launch_ms": round(kernel_ms, 4), "launches": launches,
-                         "rays_per_launch": round(rays_per_launch), "bytes_per_ray": round(B_RAY_CORNELL, 2),
-                         # algorithmic bytes count the geometry fetches that LDS serves, so `frac` can exceed what HBM sees
-                         # (`traffic`); the binding resource is VALU issue — from the same PMC profile:
-                         "binding": measured_valu()},
+            "roofline": roof,
         }
+        if not args.no_psnr:
+            out.update(psnr_vs_oracle(ptx, scene, ctx))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

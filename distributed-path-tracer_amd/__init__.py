@@ -65,7 +65,8 @@ class RenderCfg(C.Structure):
     _fields_ = [("W", C.c_uint32), ("H", C.c_uint32), ("spp", C.c_uint32), ("bounces", C.c_uint32),
                 ("env", C.c_float * 3), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
                 ("x0", C.c_uint32), ("y0", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32),
-                ("sample0", C.c_uint32), ("spp_per_pass", C.c_uint32), ("integrator", C.c_uint32)]
+                ("sample0", C.c_uint32), ("spp_per_pass", C.c_uint32), ("integrator", C.c_uint32),
+                ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("shard_tile", C.c_uint32)]
 
 
 INTEGRATOR_LIB, INTEGRATOR_WORKER = 0, 1   # ptx_integrator
@@ -303,15 +304,16 @@ class Scene:
         return out.reshape(-1, cols) if cols > 1 else out
 
     def render(self, W, H, spp, bounces, accum=None, env=(1.0, 1.0, 1.0), seed=0x5EED, tile=None, sample0=0,
-               spp_per_pass=0, want_stats=True, integrator=INTEGRATOR_LIB):
+               spp_per_pass=0, want_stats=True, integrator=INTEGRATOR_LIB, shard=None):
         """Adds radiance SUMS of samples [sample0, sample0+spp) into accum ([h,w,4] float32; numpy or torch-on-GPU).
         integrator: INTEGRATOR_LIB = core::renderer::trace, INTEGRATOR_WORKER = the HOST worker's stage pipeline.
+        shard: None, or (index, count[, tile size = 64]): only the pixels in image tiles t with t % count == index are rendered.
         Returns (accum, stats dict or None)."""
         x0, y0, w, h = tile if tile else (0, 0, W, H)
         if accum is None:
             accum = np.zeros((h, w, 4), np.float32)
         cfg = RenderCfg(W, H, spp, bounces, (C.c_float * 3)(*env), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF,
-                        x0, y0, w, h, sample0, spp_per_pass, integrator)
+                        x0, y0, w, h, sample0, spp_per_pass, integrator, *((tuple(shard) + (0,))[:3] if shard else (0, 0, 0)))
         st = RenderStats()
         _check(lib().ptx_render(self.h, C.byref(cfg), _ptr(accum), C.byref(st) if want_stats else None))
         stats = dict(rays=st.rays, samples=st.samples, passes=st.passes, kernel_ms=st.kernel_ms) if want_stats else None

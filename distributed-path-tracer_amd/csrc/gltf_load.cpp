@@ -79,13 +79,21 @@ AccessorView view(Gltf& g, size_t idx) {
 	AccessorView v;
 	v.ctype = a.at("componentType").i();
 	v.ncomp = n_components(a.at("type").s());
-	v.count = (size_t)a.at("count").i();
+	// every number below comes from the file as a signed integer: negative or absurd values must not wrap through size_t
+	const int64_t count_i = a.at("count").i();
+	const int64_t bv_off = bv.has("byteOffset") ? bv.at("byteOffset").i() : 0, a_off = a.has("byteOffset") ? a.at("byteOffset").i() : 0;
+	const int64_t stride_i = bv.has("byteStride") ? bv.at("byteStride").i() : 0, buf_i = bv.at("buffer").i();
+	if (count_i < 0 || bv_off < 0 || a_off < 0 || stride_i < 0 || buf_i < 0) fail(E_PARSE, "glTF: negative count / byteOffset / byteStride / buffer index");
+	v.count = (size_t)count_i;
 	v.normalized = a.has("normalized") && a.at("normalized").b;
-	size_t off = (bv.has("byteOffset") ? (size_t)bv.at("byteOffset").i() : 0) + (a.has("byteOffset") ? (size_t)a.at("byteOffset").i() : 0);
-	size_t elem = (size_t)component_size(v.ctype) * v.ncomp;
-	v.stride = bv.has("byteStride") && bv.at("byteStride").i() > 0 ? (size_t)bv.at("byteStride").i() : elem;
-	const std::string& buf = g.buffer((size_t)bv.at("buffer").i());
-	if (v.count && off + (v.count - 1) * v.stride + elem > buf.size()) fail(E_PARSE, "glTF: accessor exceeds its buffer");
+	const size_t elem = (size_t)component_size(v.ctype) * v.ncomp;
+	v.stride = stride_i > 0 ? (size_t)stride_i : elem;
+	const std::string& buf = g.buffer((size_t)buf_i);
+	// off + (count - 1) * stride + elem <= size, evaluated without overflow
+	const size_t size = buf.size();
+	if ((uint64_t)bv_off > size || (uint64_t)a_off > size - (size_t)bv_off) fail(E_PARSE, "glTF: accessor exceeds its buffer");
+	const size_t off = (size_t)bv_off + (size_t)a_off;
+	if (v.count && (size - off < elem || (v.count - 1) > (size - off - elem) / v.stride)) fail(E_PARSE, "glTF: accessor exceeds its buffer");
 	v.base = (const uint8_t*)buf.data() + off;
 	return v;
 }

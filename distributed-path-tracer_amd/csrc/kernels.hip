@@ -849,7 +849,9 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 				if (active) {
 					if (step == 0) {
 						const uint32_t id = (uint32_t)first + i;  // id within the pass: sample-major, pixel-minor
-						const uint32_t s_local = id / P.n_pixels, p_local = id - s_local * P.n_pixels;
+						const uint32_t s_local = id / P.n_pixels;
+						uint32_t p_local = id - s_local * P.n_pixels;
+						if (P.pixels) p_local = P.pixels[p_local];   // interleaved tile sharding: the pass renders a subset of the tile's pixels
 						const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
 						camera_ray(S, P, px, py, P.sample0 + s_local, o, d);
 						// a fresh path: T = 1, L = 0, depth = pass = 0; its RNG key (pixel, sample) travels with it (no divisions per vertex)
@@ -1235,15 +1237,16 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 }
 
 // Adds the pass's samples of each pixel, in sample order, into the accumulation buffer (sums).
-__global__ void k_resolve(const float4* __restrict__ sample_rad, float4* __restrict__ accum, uint32_t n_pixels, uint32_t pass_spp) {
+__global__ void k_resolve(const float4* __restrict__ sample_rad, float4* __restrict__ accum, const uint32_t* __restrict__ pixels, uint32_t n_pixels, uint32_t pass_spp) {
 	uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
 	if (p >= n_pixels) return;
-	float4 a = accum[p];
+	const uint32_t dst = pixels ? pixels[p] : p;   // sharded passes: sample_rad is compact over the pass's pixel list
+	float4 a = accum[dst];
 	for (uint32_t s = 0; s < pass_spp; s++) {
 		float4 r = sample_rad[(size_t)s * n_pixels + p];
 		a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
 	}
-	accum[p] = a;
+	accum[dst] = a;
 }
 
 // ------------------------------------------------------------------------------------ batch intersect
@@ -1344,8 +1347,8 @@ hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const Pa
 	if (mode == MODE_HYBRID) return launch_pass_mode<MODE_HYBRID, false>(S, P, B, lds_bytes, grid, stream);
 	return launch_pass_mode<MODE_GLOBAL, false>(S, P, B, lds_bytes, grid, stream);
 }
-hipError_t launch_resolve(const float4* sample_rad, float4* accum, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream) {
-	hipLaunchKernelGGL(k_resolve, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, sample_rad, accum, n_pixels, pass_spp);
+hipError_t launch_resolve(const float4* sample_rad, float4* accum, const uint32_t* pixels, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream) {
+	hipLaunchKernelGGL(k_resolve, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, sample_rad, accum, pixels, n_pixels, pass_spp);
 	return hipGetLastError();
 }
 template <int MODE>

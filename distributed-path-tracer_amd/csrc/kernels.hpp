@@ -77,6 +77,8 @@ struct RenderParams {
 	uint32_t seed_lo, seed_hi;
 	float env[3];
 	uint32_t integrator;        // ptx_integrator
+	const uint32_t* pixels;     // nullptr: the pass covers every pixel of the tile; else [n_pixels] tile-local pixel indices (ly * w + lx)
+	                            // of the pixels this pass renders (interleaved tile sharding), and n_pixels is the list's length
 };
 
 constexpr int kProfRegions = 16;   // PTX_PROF builds only: (wave-level trips, active lanes) per code region
@@ -102,7 +104,7 @@ struct IntersectArgs {
 
 hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, int mode, size_t lds_bytes, int grid,
                               hipStream_t stream);
-hipError_t launch_resolve(const float4* sample_rad, float4* accum, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream);
+hipError_t launch_resolve(const float4* sample_rad, float4* accum, const uint32_t* pixels, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream);
 hipError_t launch_intersect(const DevScene& S, const IntersectArgs& A, int mode, size_t lds_bytes, int grid, hipStream_t stream);
 hipError_t launch_tonemap(const float4* accum, uint32_t n_pixels, float spp, uchar4* out, hipStream_t stream);
 

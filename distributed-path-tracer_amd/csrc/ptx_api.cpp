@@ -60,8 +60,12 @@ struct ptx_ctx {
 	hipStream_t stream = nullptr;
 	int n_cu = 0;
 	std::mutex mu;
-	DevBuf queues, sample_rad, counters, spill, stage_a, stage_b;
+	DevBuf queues, sample_rad, counters, spill, stage_a, stage_b, pixel_list;
 	std::vector<hipEvent_t> events;
+	// pixel list of the last sharded render (ptx_render_cfg::shard_*), kept on the device: a frame is usually rendered again
+	// with the same sharding (sample ranges, benchmark steps)
+	uint32_t list_key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	uint32_t list_len = 0;
 };
 
 struct ptx_scene {
@@ -167,12 +171,18 @@ int upload_scene(ptx_scene* sc) {
 	return PTX_OK;
 }
 
+void release_scene_buffers(ptx_scene* sc) {
+	for (DevBuf* b : {&sc->d_models, &sc->d_surfaces, &sc->d_materials, &sc->d_nodes, &sc->d_refs, &sc->d_tris, &sc->d_vattr, &sc->d_isect, &sc->d_shade, &sc->d_tex,
+	                  &sc->d_texels, &sc->d_lut, &sc->d_spaces, &sc->d_model_space, &sc->d_res_nodes, &sc->d_res_refs, &sc->d_res_tris})
+		b->release();
+}
+
 int finish_scene(ptx_ctx* ctx, ptx_scene* sc, ptx_scene** out) {
 	sc->ctx = ctx;
 	if (ctx) {
 		std::lock_guard<std::mutex> lk(ctx->mu);
 		int rc = upload_scene(sc);
-		if (rc != PTX_OK) { delete sc; return rc; }
+		if (rc != PTX_OK) { release_scene_buffers(sc); delete sc; return rc; }
 		ctx->refs.fetch_add(1);
 	} else {
 		decide_mode(sc);
@@ -215,7 +225,7 @@ static void ctx_release(ptx_ctx* c) {
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
 	for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
-	c->queues.release(); c->spill.release(); c->sample_rad.release(); c->counters.release(); c->stage_a.release(); c->stage_b.release();
+	c->queues.release(); c->spill.release(); c->sample_rad.release(); c->counters.release(); c->stage_a.release(); c->stage_b.release(); c->pixel_list.release();
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -291,27 +301,34 @@ int ptx_worker_event_load(ptx_ctx* ctx, const char* event_json_path, const char*
 
 int ptx_scene_set_environment(ptx_scene* sc, const char* png_path, int srgb) {
 	if (!sc) return set_err(PTX_ERR_INVALID, "ptx_scene_set_environment: scene is NULL");
-	FlatScene& h = sc->host;
+	// the file is read before the lock is taken; the scene's host arrays are only touched under it (a render may be in flight on
+	// another thread: ptx_render holds the same mutex for its whole call)
+	uint32_t W = 0, H = 0, Cn = 0;
+	std::vector<uint8_t> px;
 	try {
-		if (!png_path) h.env_tex = -1;
-		else {
-			uint32_t W = 0, H = 0, Cn = 0;
-			std::vector<uint8_t> px;
-			read_png(png_path, W, H, Cn, px);
-			h.textures.push_back(TexRec{W, H, Cn | (srgb ? 256u : 0u), (uint32_t)h.texels.size()});
-			h.texels.insert(h.texels.end(), px.begin(), px.end());
-			h.texture_paths.push_back(png_path);
-			h.env_tex = (int32_t)h.textures.size() - 1;
-		}
+		if (png_path) read_png(png_path, W, H, Cn, px);
 	} catch (const Error& e) {
 		return set_err(e.code, e.msg);
 	} catch (const std::exception& e) {
 		return set_err(PTX_ERR_PARSE, e.what());
 	}
-	if (sc->ctx) {
-		std::lock_guard<std::mutex> lk(sc->ctx->mu);
-		return upload_scene(sc);   // textures changed: the whole (small) scene goes up again
+	std::unique_lock<std::mutex> lk;
+	if (sc->ctx) lk = std::unique_lock<std::mutex>(sc->ctx->mu);
+	FlatScene& h = sc->host;
+	if (h.env_tex >= 0) {   // the previous map is always the last texture (appended below): drop it instead of letting them pile up
+		const TexRec old = h.textures[(size_t)h.env_tex];
+		h.texels.resize(old.offset);
+		h.textures.pop_back();
+		h.texture_paths.pop_back();
+		h.env_tex = -1;
 	}
+	if (png_path) {
+		h.textures.push_back(TexRec{W, H, Cn | (srgb ? 256u : 0u), (uint32_t)h.texels.size()});
+		h.texels.insert(h.texels.end(), px.begin(), px.end());
+		h.texture_paths.push_back(png_path);
+		h.env_tex = (int32_t)h.textures.size() - 1;
+	}
+	if (sc->ctx) return upload_scene(sc);   // textures changed: the whole (small) scene goes up again
 	return PTX_OK;
 }
 
@@ -366,9 +383,7 @@ void ptx_scene_destroy(ptx_scene* sc) {
 		std::lock_guard<std::mutex> lk(sc->ctx->mu);
 		(void)hipSetDevice(sc->ctx->device);
 		(void)hipStreamSynchronize(sc->ctx->stream);
-		sc->d_models.release(); sc->d_surfaces.release(); sc->d_materials.release(); sc->d_nodes.release();
-		sc->d_refs.release(); sc->d_tris.release(); sc->d_vattr.release(); sc->d_isect.release(); sc->d_shade.release(); sc->d_tex.release(); sc->d_texels.release(); sc->d_lut.release(); sc->d_spaces.release(); sc->d_model_space.release();
-		sc->d_res_nodes.release(); sc->d_res_refs.release(); sc->d_res_tris.release();
+		release_scene_buffers(sc);
 	}
 	ptx_ctx* c = sc->ctx;
 	delete sc;
@@ -445,13 +460,42 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 	if (!w || !h || (uint64_t)x0 + w > cfg->W || (uint64_t)y0 + h > cfg->H) return set_err(PTX_ERR_INVALID, "ptx_render: tile outside the image");
 	if (cfg->bounces > 0xFFFFu) return set_err(PTX_ERR_INVALID, "ptx_render: bounces > 65535");
 	if (cfg->integrator > PTX_INTEGRATOR_WORKER) return set_err(PTX_ERR_INVALID, "ptx_render: unknown integrator");
+	const bool sharded = cfg->shard_count > 1;
+	if (sharded && cfg->shard_index >= cfg->shard_count) return set_err(PTX_ERR_INVALID, "ptx_render: shard_index >= shard_count");
 	ptx_ctx* c = sc->ctx;
 	std::lock_guard<std::mutex> lk(c->mu);
 	HIP_TRY(hipSetDevice(c->device));
-	const uint64_t n_pixels = (uint64_t)w * h;
-	if (n_pixels > 0x7FFFFFFFull) return set_err(PTX_ERR_INVALID, "ptx_render: tile too large");
+	const uint64_t rect_pixels = (uint64_t)w * h;
+	if (rect_pixels > 0x7FFFFFFFull) return set_err(PTX_ERR_INVALID, "ptx_render: tile too large");
 	if (stats) *stats = ptx_render_stats{};
 	if (cfg->spp == 0) return PTX_OK;
+
+	// Interleaved tile sharding: the pixels of this shard, tile by tile (rows inside a tile), as indices into the rectangle
+	uint64_t n_pixels = rect_pixels;
+	const uint32_t* d_pixels = nullptr;
+	if (sharded) {
+		const uint32_t ts = cfg->shard_tile ? cfg->shard_tile : 64u;
+		const uint32_t key[9] = {cfg->W, cfg->H, x0, y0, w, h, cfg->shard_index, cfg->shard_count, ts};
+		if (memcmp(key, c->list_key, sizeof key) != 0 || !c->pixel_list.p) {
+			std::vector<uint32_t> list;
+			const uint32_t tiles_x = (cfg->W + ts - 1) / ts;
+			for (uint32_t ty = y0 / ts; ty <= (y0 + h - 1) / ts; ty++)
+				for (uint32_t tx = x0 / ts; tx <= (x0 + w - 1) / ts; tx++) {
+					if ((uint64_t)(ty * (uint64_t)tiles_x + tx) % cfg->shard_count != cfg->shard_index) continue;
+					const uint32_t ya = std::max(ty * ts, y0), yb = std::min((ty + 1) * ts, y0 + h);
+					const uint32_t xa = std::max(tx * ts, x0), xb = std::min((tx + 1) * ts, x0 + w);
+					for (uint32_t y = ya; y < yb; y++)
+						for (uint32_t x = xa; x < xb; x++) list.push_back((y - y0) * w + (x - x0));
+				}
+			HIP_TRY(c->pixel_list.ensure(std::max<size_t>(list.size() * 4, 16)));
+			if (!list.empty()) HIP_TRY(hipMemcpy(c->pixel_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice));
+			memcpy(c->list_key, key, sizeof key);
+			c->list_len = (uint32_t)list.size();
+		}
+		n_pixels = c->list_len;
+		d_pixels = (const uint32_t*)c->pixel_list.p;
+		if (n_pixels == 0) return PTX_OK;   // no tile of this shard meets the rectangle
+	}
 
 	// samples of every pixel per launch: enough paths to fill the chip many times over, bounded workspace
 	uint32_t pass_spp = cfg->spp_per_pass;
@@ -484,9 +528,9 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 	const bool dev_accum = is_device_ptr(accum);
 	float4* d_accum = (float4*)accum;
 	if (!dev_accum) {
-		HIP_TRY(c->stage_a.ensure(n_pixels * sizeof(float4)));
+		HIP_TRY(c->stage_a.ensure(rect_pixels * sizeof(float4)));
 		d_accum = (float4*)c->stage_a.p;
-		HIP_TRY(hipMemcpyAsync(d_accum, accum, n_pixels * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipMemcpyAsync(d_accum, accum, rect_pixels * sizeof(float4), hipMemcpyHostToDevice, c->stream));
 	}
 
 	const uint32_t n_pass = (cfg->spp + pass_spp - 1) / pass_spp;
@@ -508,13 +552,14 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 		P.seed_lo = cfg->seed_lo; P.seed_hi = cfg->seed_hi;
 		memcpy(P.env, cfg->env, sizeof P.env);
 		P.integrator = cfg->integrator;
+		P.pixels = d_pixels;
 		HIP_TRY(hipMemsetAsync(chunk_counter, 0, 8, c->stream));
 		if (stats) HIP_TRY(hipEventRecord(c->events[2 * p], c->stream));
 		HIP_TRY(launch_render_pass(sc->dev, P, B, sc->mode, sc->lds_bytes, grid, c->stream));
 		if (stats) HIP_TRY(hipEventRecord(c->events[2 * p + 1], c->stream));
-		HIP_TRY(launch_resolve(B.sample_rad, d_accum, P.n_pixels, P.pass_spp, c->stream));
+		HIP_TRY(launch_resolve(B.sample_rad, d_accum, d_pixels, P.n_pixels, P.pass_spp, c->stream));
 	}
-	if (!dev_accum) HIP_TRY(hipMemcpyAsync(accum, d_accum, n_pixels * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+	if (!dev_accum) HIP_TRY(hipMemcpyAsync(accum, d_accum, rect_pixels * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
 	if (stats || !dev_accum) HIP_TRY(hipStreamSynchronize(c->stream));
 	if (stats) {
 		unsigned long long rays = 0;

@@ -174,6 +174,12 @@ typedef struct ptx_render_cfg {
 	uint32_t sample0;       /* first sample index */
 	uint32_t spp_per_pass;  /* 0 = library default; samples of every pixel traced per kernel launch */
 	uint32_t integrator;    /* ptx_integrator */
+	/* Interleaved tile sharding (one frame split over several GPUs / workers): when shard_count > 1, only
+	 * the pixels of the rectangle that lie in image tiles t with t % shard_count == shard_index are rendered, where t is the
+	 * row-major index of the shard_tile x shard_tile tile of the FULL W x H image that holds the pixel (shard_tile 0 = 64).
+	 * accum keeps the [h][w] layout of the rectangle; pixels of other shards are left untouched, so the sum of all shards'
+	 * buffers (x + 0 = x) is bitwise the unsharded frame. shard_count 0 or 1 = no sharding. */
+	uint32_t shard_index, shard_count, shard_tile;
 } ptx_render_cfg;
 typedef struct ptx_render_stats {
 	uint64_t rays;          /* closest-hit + shadow queries = renderer::intersect calls (renderer.cpp:441,509) */

@@ -21,13 +21,15 @@ class OracleScene:
     def __init__(self):
         self.s = ora.OracleScene(ora.load_gltf(CORNELL))
 
-    def render(self, W, H, spp, bounces, accum=None, sample0=0, tile=None, **kw):
+    def render(self, W, H, spp, bounces, accum=None, sample0=0, tile=None, shard=None, **kw):
         smp = self.s.render_samples(ora.make_cfg(W, H, spp, bounces, sample0=sample0, tile=tile), threads=2)   # [h,w,spp,3]
         a = accum.numpy()
+        # ptx_render_cfg.shard_*: only the pixels of this shard's interleaved tiles are touched
+        m = mg.tile_mask(shard[0], shard[1], W, H, shard[2]) if shard else np.ones((H, W), bool)
         for k in range(spp):                       # sums in sample order, like k_resolve
-            a[..., :3] += smp[:, :, k]
-            a[..., 3] += 1.0
-        return accum, {"rays": 0, "samples": W * H * spp}
+            a[..., :3][m] += smp[:, :, k][m]
+            a[..., 3][m] += 1.0
+        return accum, {"rays": 0, "samples": int(m.sum()) * spp}
 
 
 def main():
@@ -38,7 +40,9 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     accum = torch.zeros((H, W, 4), dtype=torch.float32)
     if mode == "tiles":
-        mg.render_tiles(OracleScene(), W, H, 2 * spp, b, accum, rank, world)
+        mg.render_tiles(OracleScene(), W, H, 2 * spp, b, accum, rank, world, tile=8)   # 5 x 3 tiles of 8 x 8 on the 40 x 24 frame
+    elif mode == "strong":
+        mg.render_samples(OracleScene(), W, H, 2 * spp, b, accum, rank, world)
     else:
         mg.render_sharded(OracleScene(), W, H, spp, b, accum, rank, world)
     if rank == 0:

@@ -223,20 +223,38 @@ def test_device_buffers_via_torch(scene, ctx):
 
 
 def test_tile_sharding_on_device_buffers(scene, ptx):
-    """multigpu.render_tiles (strong scaling): two "ranks" run one after the other on this GPU, each into its band of one
-    device-resident frame: bitwise the single-GPU frame."""
+    """multigpu.render_tiles (strong scaling, interleaved 64 x 64 tiles = ptx_render_cfg.shard_*): three "ranks" run one after the
+    other on this GPU, each into its tiles of one device-resident zeroed frame: bitwise the single-GPU frame. Also with ragged edge
+    tiles (16 x 16 on 160 x 90), inside a sub-rectangle, and with host buffers."""
     import importlib
     import torch
     mg = importlib.import_module("distributed-path-tracer_amd.multigpu")
-    W, H, spp, b = 160, 90, 4, 5
+    for (W, H, spp, b, ts) in ((160, 90, 4, 5, 16), (448, 200, 2, 4, 64)):
+        full, fst = scene.render(W, H, spp, b)
+        acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+        rays, samples = 0, 0
+        for r in range(3):
+            st = mg.render_tiles(scene, W, H, spp, b, acc, r, 3, tile=ts, want_stats=True)
+            rays += st["rays"]; samples += st["samples"]
+            # after rank r, exactly the pixels of ranks 0..r are filled
+            part = acc.cpu().numpy()
+            done = np.zeros((H, W), bool)
+            for q in range(r + 1):
+                done |= mg.tile_mask(q, 3, W, H, ts)
+            assert (part[..., 3][done] == spp).all() and (part[~done] == 0).all()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(acc.cpu().numpy(), full)
+        assert rays == fst["rays"] and samples == W * H * spp
+    # a shard of a sub-rectangle, host buffer: tiles are those of the FULL image grid
+    W, H, spp, b = 160, 90, 3, 4
     full, _ = scene.render(W, H, spp, b)
-    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
-    rays = 0
-    for r in range(3):
-        rays += mg.render_tiles(scene, W, H, spp, b, acc, r, 3, want_stats=True)["rays"]
-    torch.cuda.synchronize()
-    np.testing.assert_array_equal(acc.cpu().numpy(), full)
-    assert rays > 0
+    x0, y0, w, h = 24, 10, 100, 61
+    sub = np.zeros((h, w, 4), np.float32)
+    for r in range(2):
+        scene.render(W, H, spp, b, accum=sub, tile=(x0, y0, w, h), shard=(r, 2, 16))
+    np.testing.assert_array_equal(sub, full[y0:y0 + h, x0:x0 + w])
+    with pytest.raises(ptx.PtxError):
+        scene.render(W, H, 1, b, shard=(2, 2, 16))
 
 
 def test_reduce_framebuffer_through_rccl(scene, ctx, ptx):
@@ -500,7 +518,11 @@ def test_environment_map_matches_oracle(ptx, ctx, ora, tmp_path):
     mean, _ = o.render(ora.make_cfg(160, 90, 8, 5), threads=0)
     accum, _ = s.render(160, 90, 8, 5)
     assert ora.psnr8(ctx.tonemap_encode(accum, 160, 90, 8), ora.tonemap_write(mean)) >= 40.0
+    n_tex = s.info()["n_textures"]
+    s.set_environment(png, True)                                        # setting a map again REPLACES the previous one
+    assert s.info()["n_textures"] == n_tex
     s.set_environment(None)
+    assert s.info()["n_textures"] == n_tex - 1
     again, _ = s.render(80, 45, 2, 5, env=(0.7, 0.9, 1.3))
     np.testing.assert_array_equal(again, plain)
     with pytest.raises(ptx.PtxError) as e:

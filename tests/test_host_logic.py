@@ -359,6 +359,15 @@ def test_malformed_gltf_is_an_error_not_a_crash(ptx, tmp_path):
     assert attempt(base, bin_bytes=binb[:len(binb) // 2]) == "error"
     muts = [lambda d: d["bufferViews"][0].__setitem__("byteOffset", 10 ** 9),
             lambda d: d["accessors"][0].__setitem__("count", 10 ** 8),
+            # values that would wrap through size_t in `offset + (count - 1) * stride + element`: negative, or near 2^63
+            lambda d: d["bufferViews"][0].__setitem__("byteOffset", -16),
+            lambda d: d["accessors"][0].__setitem__("byteOffset", -4),
+            lambda d: d["accessors"][0].__setitem__("count", -1),
+            lambda d: d["accessors"][0].__setitem__("count", 2 ** 62),
+            lambda d: d["bufferViews"][0].__setitem__("byteStride", 2 ** 62),
+            lambda d: d["bufferViews"][0].__setitem__("byteStride", -8),
+            lambda d: d["bufferViews"][0].__setitem__("byteOffset", 2 ** 63 - 1),
+            lambda d: d["bufferViews"][0].__setitem__("buffer", -1),
             lambda d: d["accessors"][0].__setitem__("bufferView", 999),
             lambda d: d["accessors"][0].__setitem__("componentType", 1234),
             lambda d: d["accessors"][0].__setitem__("type", "MAT4"),

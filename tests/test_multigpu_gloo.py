@@ -19,11 +19,13 @@ def test_sample_partitions():
             assert sum(n for _, n in parts) == total
             assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(world - 1))   # contiguous, disjoint
             assert max(n for _, n in parts) - min(n for _, n in parts) <= 1
-        for H in (0, 1, 7, 1080, 2160):
-            bands = [mg.tile_rows(r, world, H) for r in range(world)]
-            assert sum(h for _, h in bands) == H and bands[0][0] == 0
-            assert all(bands[i][0] + bands[i][1] == bands[i + 1][0] for i in range(world - 1))
-            assert max(h for _, h in bands) - min(h for _, h in bands) <= 1
+        for (W, H) in ((1, 1), (65, 7), (1920, 1080), (3840, 2160)):
+            masks = [mg.tile_mask(r, world, W, H) for r in range(world)]
+            assert (np.sum(masks, axis=0) == 1).all()                       # every pixel belongs to exactly one rank
+            assert masks[mg.tile_owner(W - 1, H - 1, W, world)][H - 1, W - 1]
+            if W * H > 64 * 64 * 4 * world:                                  # interleaving balances the ranks (pixels, hence cost)
+                n = [int(m.sum()) for m in masks]
+                assert max(n) - min(n) <= 0.04 * W * H / world + 64 * 64, n
     with pytest.raises(ValueError):
         mg.sample_range(2, 2, 4)
 
@@ -47,8 +49,28 @@ def test_two_rank_framebuffer_reduce_equals_single_rank(tmp_path, cornell_oracle
     np.testing.assert_allclose(got[..., :3], ref[..., :3], rtol=2e-6, atol=1e-6)
 
 
+def test_two_rank_strong_sample_split(tmp_path, cornell_oracle, ora):
+    """Strong scaling by samples (the bench default for N > 1): two ranks trace samples [0,3) and [3,6) of ONE 6-spp frame."""
+    out = str(tmp_path / "strong.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29521", os.path.join(ROOT, "tests", "_dist_worker.py"), out, "strong"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out)
+    W, H, spp, b = 40, 24, 6, 4
+    smp = cornell_oracle.render_samples(ora.make_cfg(W, H, spp, b), threads=4)
+    ref = np.zeros((H, W, 4), np.float32)
+    for k in range(spp):
+        ref[..., :3] += smp[:, :, k]
+        ref[..., 3] += 1.0
+    np.testing.assert_array_equal(got[..., 3], ref[..., 3])
+    np.testing.assert_allclose(got[..., :3], ref[..., :3], rtol=2e-6, atol=1e-6)
+
+
 def test_two_rank_tile_sharding_is_bitwise_the_single_rank_frame(tmp_path, cornell_oracle, ora):
-    """Strong scaling: two ranks render the two halves of one frame; the sum-reduce of (band, zeros) assembles exactly the frame."""
+    """Strong scaling by interleaved tiles: two ranks render alternating 8 x 8 tiles of one frame into zeroed full-frame buffers;
+    the sum-reduce of (tile, zeros) assembles exactly the frame."""
     out = str(tmp_path / "tiles.npy")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
