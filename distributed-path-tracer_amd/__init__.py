@@ -151,6 +151,7 @@ def lib():
         L.ptx_render.argtypes = [C.c_void_p, C.POINTER(RenderCfg), C.c_void_p, C.POINTER(RenderStats)]
         L.ptx_intersect_batch.argtypes = [C.c_void_p, C.POINTER(Rays), C.c_size_t, C.POINTER(Hits)]
         L.ptx_tonemap_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.ptx_pbr_eval_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.ptx_reduce_framebuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.ptx_encode_png.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.ptx_free.argtypes = [C.c_void_p]
@@ -198,6 +199,14 @@ class Context:
         n = int(accum.numel()) if hasattr(accum, "numel") else int(accum.size)
         comm = nccl_comm if isinstance(nccl_comm, C.c_void_p) else C.c_void_p(int(nccl_comm))
         _check(lib().ptx_reduce_framebuffer(self.h, comm, _ptr(accum), n, root))
+
+    def pbr_eval(self, records):
+        """ptx_pbr_eval_batch: records [n,14] float32 (normal, outcoming, incoming, u1, u2, roughness, cos_theta, ior) ->
+        [n,15] float32 (rand_cone_vec, importance_diffuse, importance_specular, pdf_diffuse, pdf_specular, fresnel, reflect)."""
+        a = np.ascontiguousarray(records, np.float32).reshape(-1, 14)
+        out = np.zeros((len(a), 15), np.float32)
+        _check(lib().ptx_pbr_eval_batch(self.h, a.ctypes.data, len(a), out.ctypes.data))
+        return out
 
     def tonemap_encode(self, accum, W, H, spp, out=None):
         """accum: [H,W,4] float32 sums (numpy or torch-on-GPU). Returns/filles RGBA8 [H,W,4]."""

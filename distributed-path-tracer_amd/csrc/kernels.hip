@@ -1281,6 +1281,28 @@ __global__ void __launch_bounds__(kBlock) k_intersect_batch(DevScene S0, Interse
 	}
 }
 
+// ------------------------------------------------------------------------------------ batch BSDF functions
+// The sampling / pdf functions exactly as k_render_pass inlines them, one record per lane (ptx_pbr_eval_batch).
+__global__ void k_pbr_eval(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float* p = in + 14 * i;
+	const V3 nrm = mk(p[0], p[1], p[2]), o = mk(p[3], p[4], p[5]), inc = mk(p[6], p[7], p[8]);
+	const float u1 = p[9], u2 = p[10], rough = p[11], cos_theta = p[12], ior = p[13];
+	const V3 cone = rand_cone_vec(u2, cos_theta, nrm);
+	const V3 idf = importance_sample(false, u1, u2, nrm, o, rough);
+	const V3 isp = importance_sample(true, u1, u2, nrm, o, rough);
+	const V3 rf = reflect3(-o, nrm);
+	float* q = out + 15 * i;
+	q[0] = cone.x; q[1] = cone.y; q[2] = cone.z;
+	q[3] = idf.x; q[4] = idf.y; q[5] = idf.z;
+	q[6] = isp.x; q[7] = isp.y; q[8] = isp.z;
+	q[9] = pdf_diffuse(nrm, inc);
+	q[10] = pdf_specular(nrm, o, inc, rough);
+	q[11] = fresnel_schlick(o, rf, ior);
+	q[12] = rf.x; q[13] = rf.y; q[14] = rf.z;
+}
+
 // ------------------------------------------------------------------------------------ tonemap + encode
 // core::tonemap_approx_aces (core/utils.hpp:29-36) + image::image::write (image/image.cpp:143-154)
 DEV float aces1(float x) {
@@ -1290,18 +1312,27 @@ DEV float aces1(float x) {
 	return v;
 }
 DEV uint32_t quant8(float v) { return (uint32_t)(uint8_t)(int)(v * 255 + 0.5F); }
-__global__ void k_tonemap(const float4* __restrict__ accum, uint32_t n_pixels, float spp, uchar4* __restrict__ out) {
+// image::write on a colour channel of an sRGB image: static_cast<uint8_t>(math::pow(value, 1 / 2.2F) * 255 + 0.5F) — the pow is glibc's
+// powf, which no other implementation reproduces bit for bit, and a 1-ulp difference flips a byte whenever value * 255 + 0.5 lands on an
+// integer. The byte is a non-decreasing step function of value on [0, 1] (checked over every float of the interval,
+// tests/test_oracle_vs_reference.py), so it is evaluated here as such: thr[k] = the smallest value whose byte is >= k, found on the
+// host with that same powf (ptx_api.cpp: srgb_thresholds), and an 8-step binary search per channel. A NaN compares false: byte 0, as
+// the reference's float -> int conversion of NaN gives after truncation to 8 bits.
+DEV uint32_t srgb8(const float* __restrict__ thr, float v) {
+	uint32_t k = 0;
+#pragma unroll
+	for (uint32_t step = 128; step; step >>= 1)
+		if (v >= thr[k + step]) k += step;
+	return k;
+}
+__global__ void k_tonemap(const float4* __restrict__ accum, uint32_t n_pixels, float spp, const float* __restrict__ thr, uchar4* __restrict__ out) {
 	uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
 	if (p >= n_pixels) return;
 	float4 a = accum[p];
-	float r = aces1(a.x / spp), g = aces1(a.y / spp), b = aces1(a.z / spp);
-	// math::pow(value, 1 / 2.2F) is powf; evaluated here in double and rounded once so that the result is
-	// the correctly rounded float in all but ~1e-8 of cases (glibc's powf is within 1 ulp of it)
-	const double ig = (double)(1 / 2.2F);
 	uchar4 o;
-	o.x = (unsigned char)quant8((float)pow((double)r, ig));
-	o.y = (unsigned char)quant8((float)pow((double)g, ig));
-	o.z = (unsigned char)quant8((float)pow((double)b, ig));
+	o.x = (unsigned char)srgb8(thr, aces1(a.x / spp));
+	o.y = (unsigned char)srgb8(thr, aces1(a.y / spp));
+	o.z = (unsigned char)srgb8(thr, aces1(a.z / spp));
 	o.w = (unsigned char)quant8(a.w / spp);
 	out[p] = o;
 }
@@ -1365,8 +1396,12 @@ hipError_t launch_intersect(const DevScene& S, const IntersectArgs& A, int mode,
 	if (mode == MODE_HYBRID) return launch_intersect_mode<MODE_HYBRID>(S, A, lds_bytes, grid, stream);
 	return launch_intersect_mode<MODE_GLOBAL>(S, A, lds_bytes, grid, stream);
 }
-hipError_t launch_tonemap(const float4* accum, uint32_t n_pixels, float spp, uchar4* out, hipStream_t stream) {
-	hipLaunchKernelGGL(k_tonemap, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, accum, n_pixels, spp, out);
+hipError_t launch_pbr_eval(const float* in, float* out, size_t n, hipStream_t stream) {
+	hipLaunchKernelGGL(k_pbr_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, out, n);
+	return hipGetLastError();
+}
+hipError_t launch_tonemap(const float4* accum, uint32_t n_pixels, float spp, const float* thresholds, uchar4* out, hipStream_t stream) {
+	hipLaunchKernelGGL(k_tonemap, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, accum, n_pixels, spp, thresholds, out);
 	return hipGetLastError();
 }
 

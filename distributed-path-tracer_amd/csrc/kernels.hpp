@@ -106,6 +106,7 @@ hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const Pa
                               hipStream_t stream);
 hipError_t launch_resolve(const float4* sample_rad, float4* accum, const uint32_t* pixels, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream);
 hipError_t launch_intersect(const DevScene& S, const IntersectArgs& A, int mode, size_t lds_bytes, int grid, hipStream_t stream);
-hipError_t launch_tonemap(const float4* accum, uint32_t n_pixels, float spp, uchar4* out, hipStream_t stream);
+hipError_t launch_pbr_eval(const float* in, float* out, size_t n, hipStream_t stream);
+hipError_t launch_tonemap(const float4* accum, uint32_t n_pixels, float spp, const float* thresholds /* [256], device */, uchar4* out, hipStream_t stream);
 
 }  // namespace ptx

@@ -50,6 +50,26 @@ struct DevBuf {
 	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// image::write's quantiser for sRGB colour channels as a step function (kernels.hip: srgb8): thr[k] = the smallest float v in [0, 1]
+// with byte(v) >= k, byte(v) = static_cast<uint8_t>(powf(v, 1 / 2.2F) * 255 + 0.5F) evaluated with this process's libm — the
+// reference's own call (image.cpp:143-154). Floats in [0, 1] order like their bit patterns, so each threshold is a bisection over bits.
+void srgb_thresholds(float thr[256]) {
+	auto byte_of = [](uint32_t bits) {
+		float v;
+		memcpy(&v, &bits, 4);
+		return (uint32_t)(uint8_t)(std::pow(v, 1 / 2.2F) * 255 + 0.5F);
+	};
+	thr[0] = 0.0f;
+	for (uint32_t k = 1; k < 256; k++) {
+		uint32_t lo = 0, hi = 0x3F800000u;   // byte(lo) = 0 < k <= 255 = byte(hi)
+		while (hi - lo > 1) {
+			const uint32_t mid = lo + (hi - lo) / 2;
+			if (byte_of(mid) >= k) hi = mid; else lo = mid;
+		}
+		memcpy(&thr[k], &hi, 4);
+	}
+}
+
 constexpr size_t kLdsBudget = 160 * 1024;  // per-CU LDS on gfx950; one workgroup may take all of it
 
 }  // namespace
@@ -60,7 +80,7 @@ struct ptx_ctx {
 	hipStream_t stream = nullptr;
 	int n_cu = 0;
 	std::mutex mu;
-	DevBuf queues, sample_rad, counters, spill, stage_a, stage_b, pixel_list;
+	DevBuf queues, sample_rad, counters, spill, stage_a, stage_b, pixel_list, srgb_thr;
 	std::vector<hipEvent_t> events;
 	// pixel list of the last sharded render (ptx_render_cfg::shard_*), kept on the device: a frame is usually rendered again
 	// with the same sharding (sample ranges, benchmark steps)
@@ -225,7 +245,7 @@ static void ctx_release(ptx_ctx* c) {
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
 	for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
-	c->queues.release(); c->spill.release(); c->sample_rad.release(); c->counters.release(); c->stage_a.release(); c->stage_b.release(); c->pixel_list.release();
+	c->queues.release(); c->spill.release(); c->sample_rad.release(); c->counters.release(); c->stage_a.release(); c->stage_b.release(); c->pixel_list.release(); c->srgb_thr.release();
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -638,6 +658,32 @@ int ptx_intersect_batch(ptx_scene* sc, const ptx_rays* r, size_t n, const ptx_hi
 	return PTX_OK;
 }
 
+int ptx_pbr_eval_batch(ptx_ctx* c, const float* in, size_t n, float* out) {
+	if (!c) return set_err(PTX_ERR_NO_DEVICE, "ptx_pbr_eval_batch: no GPU context (no CPU path exists)");
+	if (n == 0) return PTX_OK;
+	if (!in || !out) return set_err(PTX_ERR_INVALID, "ptx_pbr_eval_batch: NULL argument");
+	if (n > (size_t)0x7FFFFFFF) return set_err(PTX_ERR_INVALID, "ptx_pbr_eval_batch: batch too large");
+	std::lock_guard<std::mutex> lk(c->mu);
+	HIP_TRY(hipSetDevice(c->device));
+	const bool dev = is_device_ptr(in);
+	if (dev != is_device_ptr(out)) return set_err(PTX_ERR_INVALID, "ptx_pbr_eval_batch: in and out must both be device or both be host memory");
+	const float* d_in = in;
+	float* d_out = out;
+	if (!dev) {
+		HIP_TRY(c->stage_a.ensure(n * 14 * 4));
+		HIP_TRY(c->stage_b.ensure(n * 15 * 4));
+		HIP_TRY(hipMemcpyAsync(c->stage_a.p, in, n * 14 * 4, hipMemcpyHostToDevice, c->stream));
+		d_in = (const float*)c->stage_a.p;
+		d_out = (float*)c->stage_b.p;
+	}
+	HIP_TRY(launch_pbr_eval(d_in, d_out, n, c->stream));
+	if (!dev) {
+		HIP_TRY(hipMemcpyAsync(out, d_out, n * 15 * 4, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	return PTX_OK;
+}
+
 int ptx_reduce_framebuffer(ptx_ctx* c, void* nccl_comm, float* accum, size_t n_floats, int root) {
 	if (!c || !nccl_comm || !accum) return set_err(PTX_ERR_INVALID, "ptx_reduce_framebuffer: NULL argument");
 	if (!is_device_ptr(accum)) return set_err(PTX_ERR_INVALID, "ptx_reduce_framebuffer: accum must be device memory");
@@ -676,7 +722,13 @@ int ptx_tonemap_encode(ptx_ctx* c, const float* accum, uint32_t W, uint32_t H, u
 		HIP_TRY(c->stage_b.ensure(n * 4));
 		d_out = (uchar4*)c->stage_b.p;
 	}
-	HIP_TRY(launch_tonemap(d_in, (uint32_t)n, (float)spp, d_out, c->stream));
+	if (!c->srgb_thr.p) {
+		float thr[256];
+		srgb_thresholds(thr);
+		HIP_TRY(c->srgb_thr.ensure(sizeof thr));
+		HIP_TRY(hipMemcpy(c->srgb_thr.p, thr, sizeof thr, hipMemcpyHostToDevice));
+	}
+	HIP_TRY(launch_tonemap(d_in, (uint32_t)n, (float)spp, (const float*)c->srgb_thr.p, d_out, c->stream));
 	if (!dev_out) {
 		HIP_TRY(hipMemcpyAsync(rgba8, d_out, n * 4, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));

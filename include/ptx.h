@@ -208,6 +208,16 @@ typedef struct ptx_hits {
 } ptx_hits;
 int ptx_intersect_batch(ptx_scene* scene, const ptx_rays* rays, size_t n, const ptx_hits* hits);
 
+/* Batch form of the SHADING stage's sampling functions — core::pbr::importance_diffuse / importance_specular / pdf_diffuse /
+ * pdf_specular / fresnel (LIB/core/pbr.cpp:71-184), util::rand_cone_vec (LIB/util/rand_cone_vec.cpp:8-35) and core::reflect
+ * (LIB/core/utils.hpp:38-40) — evaluated by the same device functions the integrator kernel inlines. Function-level check of the
+ * GPU's libm (ocml sin / cos / acos) against the reference's (glibc), and the unit a host SHADING stage queue would call.
+ * in [n][14]: normal(3) outcoming(3) incoming(3) u1 u2 roughness cos_theta ior;
+ * out[n][15]: rand_cone_vec(u2, cos_theta, normal)(3), importance_diffuse((u1,u2), normal)(3), importance_specular((u1,u2), normal,
+ * outcoming, roughness)(3), pdf_diffuse(normal, incoming), pdf_specular(normal, outcoming, incoming, roughness),
+ * fresnel(outcoming, reflect(-outcoming, normal), ior), reflect(-outcoming, normal)(3). Pointers device or host (both of one kind). */
+int ptx_pbr_eval_batch(ptx_ctx* ctx, const float* in, size_t n, float* out);
+
 /* ---- multi-GPU fan-in ------------------------------------------------------------------------------
  * The one exchange step of the path: the sum of the per-rank accumulation buffers on rank `root`. Replaces the
  * reference's planned (never implemented) SNS/SQS result fan-in (src/models/work_info.hpp:22-23,

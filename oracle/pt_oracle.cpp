@@ -1076,6 +1076,38 @@ void ora_tonemap_write(size_t n, const float* in, uint8_t* out) {
 		out[4 * i + 3] = (uint8_t)(in[4 * i + 3] * 255 + 0.5F);
 	}
 }
+// image::write's sRGB quantiser over EVERY float of [0, 1] (bit patterns 0 .. 0x3F800000): is the byte a non-decreasing function of
+// the value? first[k] = bits of the smallest value whose byte is >= k (0 for k = 0); returns the number of adjacent pairs where the
+// byte DEcreases (0 = monotone: the product may then evaluate the quantiser as a 255-step function, kernels.hip srgb8).
+uint64_t ora_srgb8_scan(uint32_t* first /*[256]*/, int threads) {
+	if (threads < 1) threads = (int)std::thread::hardware_concurrency();
+	const uint64_t N = 0x3F800000ull + 1;
+	std::vector<uint64_t> bad(threads, 0);
+	std::vector<std::vector<uint32_t>> firsts(threads, std::vector<uint32_t>(256, 0xFFFFFFFFu));
+	auto work = [&](int t) {
+		const uint64_t a = N * t / threads, b = N * (t + 1) / threads;
+		auto q = [](uint32_t bits) { float v; memcpy(&v, &bits, 4); return (uint32_t)to_srgb8(v); };
+		uint32_t prev = a ? q((uint32_t)a - 1) : 0;
+		for (uint64_t i = a; i < b; i++) {
+			const uint32_t c = q((uint32_t)i);
+			if (c < prev) bad[t]++;
+			for (uint32_t k = prev + 1; k <= c; k++) if (firsts[t][k] == 0xFFFFFFFFu) firsts[t][k] = (uint32_t)i;
+			prev = c;
+		}
+	};
+	std::vector<std::thread> th;
+	for (int t = 0; t < threads; t++) th.emplace_back(work, t);
+	for (auto& t : th) t.join();
+	uint64_t nb = 0;
+	for (int k = 0; k < 256; k++) first[k] = 0xFFFFFFFFu;
+	first[0] = 0;
+	for (int t = 0; t < threads; t++) {
+		nb += bad[t];
+		for (int k = 1; k < 256; k++) if (firsts[t][k] < first[k]) first[k] = firsts[t][k];
+	}
+	return nb;
+}
+
 void ora_philox(size_t n, const uint32_t* ctr /*[n][4]*/, const uint32_t* key /*[n][2]*/, uint32_t* out /*[n][4]*/) {
 	for (size_t i = 0; i < n; i++) {
 		u4 r = philox4x32_10({ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3]}, key[2 * i], key[2 * i + 1]);

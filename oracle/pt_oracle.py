@@ -466,6 +466,14 @@ def tonemap_write(rgba):
     lib().ora_tonemap_write(C.c_size_t(len(a)), _p(a), _p(out)); return out.reshape(np.shape(rgba))
 
 
+def srgb8_scan(threads=0):
+    """image::write's sRGB quantiser over every float of [0, 1]: -> (first bits [256] uint32, number of places where the byte decreases)."""
+    first = np.zeros(256, np.uint32)
+    lib().ora_srgb8_scan.restype = C.c_uint64
+    bad = lib().ora_srgb8_scan(_p(first), C.c_int(threads))
+    return first, int(bad)
+
+
 def philox(ctr, key):
     ctr = np.ascontiguousarray(ctr, np.uint32).reshape(-1, 4); key = np.ascontiguousarray(key, np.uint32).reshape(-1, 2)
     out = np.zeros_like(ctr)

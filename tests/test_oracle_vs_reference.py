@@ -226,3 +226,18 @@ def test_cornell_mean_image_statistics(cornell_oracle, ora, gold_mean):
         noise = rl2(ra, rb)
         assert rl2(o, ra) < 1.1 * noise and rl2(o, rb) < 1.1 * noise, (tag, rl2(o, ra), rl2(o, rb), noise)
         assert abs(o.mean() / ((ra.mean() + rb.mean()) / 2) - 1) < 0.005, tag
+
+
+def test_srgb_quantiser_is_a_monotone_step_function(ora, gold_vec):
+    """image::write (image.cpp:143-154): byte = uint8(powf(v, 1/2.2f) * 255 + 0.5f). Over EVERY float of [0, 1] (1.07e9 values, glibc
+    powf) the byte never decreases, so the product may evaluate it as a 255-threshold step function (kernels.hip srgb8) and be exact
+    against the reference's bytes. The thresholds found here reproduce the reference's fixture bytes."""
+    first, decreasing = ora.srgb8_scan()
+    assert decreasing == 0
+    assert first[0] == 0 and (np.diff(first.astype(np.int64)) > 0).all() and first[255] <= 0x3F800000
+    thr = first.view(np.float32)
+    tin = gold_vec["tone_in"].reshape(-1, 4)
+    x = tin[:, :3]
+    v = np.clip((x * (np.float32(2.51) * x + np.float32(0.03))) / (x * (np.float32(2.43) * x + np.float32(0.59)) + np.float32(0.14)), 0, 1).astype(np.float32)
+    got = (np.searchsorted(thr[1:], v.reshape(-1), side="right")).reshape(v.shape)        # number of thresholds <= v
+    np.testing.assert_array_equal(got, gold_vec["tone_out"].reshape(-1, 4)[:, :3])
