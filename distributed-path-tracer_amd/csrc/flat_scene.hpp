@@ -161,6 +161,8 @@ struct Error {
 	std::string msg;
 };
 void read_png(const std::string& path, uint32_t& W, uint32_t& H, uint32_t& C, std::vector<uint8_t>& out);
+void read_jpeg(const std::string& path, uint32_t& W, uint32_t& H, uint32_t& C, std::vector<uint8_t>& out);    // jpeg_read.cpp
+void read_image(const std::string& path, uint32_t& W, uint32_t& H, uint32_t& C, std::vector<uint8_t>& out);   // PNG or JPEG, by content
 // work: the host's `scene_info.work` primitive filter (src/models/work_info.hpp:11-15, src/scene/load_gltf.cpp:95-99):
 // when `filter` is set, only the listed primitive indices of each named mesh are loaded (a mesh that is not listed
 // loads nothing but keeps its model); when clear, every primitive is loaded (core::renderer::load_gltf).

@@ -183,7 +183,7 @@ struct Loader {
 		if (it != tex_by_path.end()) return it->second;
 		uint32_t W, H, C;
 		std::vector<uint8_t> px;
-		read_png(path, W, H, C, px);
+		read_image(path, W, H, C, px);   // PNG or JPEG, by content (image::image::load -> stb_image)
 		if (texels.size() + px.size() > 0xFFFFFFFFull) fail(E_PARSE, "glTF: more than 4 GiB of texels");
 		TexRec t{W, H, C | (srgb ? 256u : 0u), (uint32_t)texels.size()};
 		texels.insert(texels.end(), px.begin(), px.end());

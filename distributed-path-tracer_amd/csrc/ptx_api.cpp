@@ -326,7 +326,7 @@ int ptx_scene_set_environment(ptx_scene* sc, const char* png_path, int srgb) {
 	uint32_t W = 0, H = 0, Cn = 0;
 	std::vector<uint8_t> px;
 	try {
-		if (png_path) read_png(png_path, W, H, Cn, px);
+		if (png_path) read_image(png_path, W, H, Cn, px);   // PNG or JPEG
 	} catch (const Error& e) {
 		return set_err(e.code, e.msg);
 	} catch (const std::exception& e) {

@@ -70,15 +70,75 @@ def pack(src_dir, dst):
     print(f"{dst}: {len(arrs)} arrays, {os.path.getsize(dst) / 1024:.0f} KiB")
 
 
+SPONZA_TEX = "/root/reference/path-tracer-core/scenes/sponza-new/textures"
+
+
+def make_jpeg_fixtures(env):
+    """JPEG textures (image::image::load -> stb_image v2.30): decoded pixels and bilinear lookups of the compiled reference on
+    (a) two of the reference's own Sponza textures, copied as data, (b) small synthetic files written here with Pillow that cover what
+    the 63 Sponza files (all baseline 4:4:4) do not: 4:2:0 / 4:2:2 / 4:1:1 chroma, progressive, restart intervals, grey, odd sizes,
+    extreme quality; (c) SHA-256 digests of the decoded pixels of ALL 63 Sponza JPEGs (checked where the reference tree is present)."""
+    import hashlib
+    import shutil
+    from PIL import Image
+    jd = os.path.join(GOLD, "jpeg")
+    os.makedirs(jd, exist_ok=True)
+    rng = np.random.default_rng(3)
+
+    def img(w, h):
+        y, x = np.mgrid[0:h, 0:w]
+        a = np.stack([127 + 120 * np.sin(x / 7.0) * np.cos(y / 5.0), 255 * x / max(w - 1, 1), 255 * y / max(h - 1, 1)], -1) + rng.normal(0, 12, (h, w, 3))
+        return Image.fromarray(np.clip(a, 0, 255).astype(np.uint8), "RGB")
+    cases = {"s444": dict(size=(67, 45), subsampling=0, quality=90), "s420": dict(size=(67, 45), subsampling=2, quality=85),
+             "s422": dict(size=(64, 48), subsampling=1, quality=75), "s411": dict(size=(70, 50), subsampling="4:1:1", quality=80),
+             "s420_1x1": dict(size=(1, 1), subsampling=2, quality=90), "s420_odd": dict(size=(17, 9), subsampling=2, quality=50),
+             "prog444": dict(size=(67, 45), subsampling=0, quality=88, progressive=True), "prog420": dict(size=(70, 41), subsampling=2, quality=80, progressive=True),
+             "opt420": dict(size=(96, 64), subsampling=2, quality=95, optimize=True), "q10": dict(size=(80, 56), subsampling=2, quality=10),
+             "q100": dict(size=(40, 40), subsampling=0, quality=100), "rst_blocks": dict(size=(100, 75), subsampling=2, quality=80, restart_marker_blocks=3),
+             "rst_rows": dict(size=(100, 75), subsampling=0, quality=80, restart_marker_rows=1),
+             "rst_prog": dict(size=(90, 70), subsampling=2, quality=80, restart_marker_rows=1, progressive=True)}
+    for n, c in cases.items():
+        sz = c.pop("size")
+        img(*sz).save(os.path.join(jd, n + ".jpg"), **c)
+    img(61, 47).convert("L").save(os.path.join(jd, "gray.jpg"), quality=80)
+    img(61, 47).convert("L").save(os.path.join(jd, "gray_prog.jpg"), quality=80, progressive=True)
+    for k, name in enumerate(("16885566240357350108.jpg", "8503262930880235456.jpg")):   # the two smallest Sponza textures (12 KB, 102 KB)
+        shutil.copyfile(os.path.join(SPONZA_TEX, name), os.path.join(jd, f"sponza_{k}.jpg"))
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for f in sorted(glob.glob(os.path.join(jd, "*.jpg"))):
+            tag = os.path.basename(f)[:-4]
+            subprocess.check_call([HARNESS, "image", f, tmp, "21", "192"], env=env)
+            px = np.load(os.path.join(tmp, "pixels.npy"))
+            out[tag + "_shape"] = np.array(px.shape, np.int32)
+            out[tag + "_sha"] = sha(px)
+            if px.size <= 40000:
+                out[tag + "_pixels"] = px
+            for k in ("uv", "sample_linear", "sample_srgb"):
+                out[f"{tag}_{k}"] = np.load(os.path.join(tmp, k + ".npy"))
+        names, digests = [], []
+        for f in sorted(glob.glob(os.path.join(SPONZA_TEX, "*.jpg"))):
+            subprocess.check_call([HARNESS, "image", f, tmp, "1", "1"], env=env)
+            names.append(os.path.basename(f)); digests.append(sha(np.load(os.path.join(tmp, "pixels.npy"))))
+        out["sponza_names"] = np.array(names)
+        out["sponza_sha"] = np.stack(digests)
+    np.savez_compressed(os.path.join(GOLD, "jpeg_vectors.npz"), **out)
+    print(f"jpeg_vectors.npz written ({os.path.getsize(os.path.join(GOLD, 'jpeg_vectors.npz')) / 1024:.0f} KiB), {len(names)} Sponza digests")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--no-mean", action="store_true")
     ap.add_argument("--only-trace", action="store_true", help="regenerate trace_vectors.npz only")
+    ap.add_argument("--only-jpeg", action="store_true", help="regenerate tests/golden/jpeg/* and jpeg_vectors.npz only")
     ap.add_argument("--n", type=int, default=1024)
     args = ap.parse_args()
     subprocess.check_call(["make", "-s", "-j8", "-C", HERE, "ref"])
     os.makedirs(GOLD, exist_ok=True)
     env = dict(os.environ, ORACLE_SEED="20261004")
+    if args.only_jpeg:
+        make_jpeg_fixtures(env)
+        return
     with tempfile.TemporaryDirectory() as tmp:
         # ---- renderer::trace itself: n rays traced one after the other by ONE thread on ONE seeded mt19937 stream. Pins the
         # integrator's COMPOSITION (draw order, lobe choice, sun block, BRDF / PDF combine, clamp, emissive x 10, opacity
@@ -138,6 +198,7 @@ def main():
         d = os.path.join(tmp, "env")
         subprocess.check_call([HARNESS, "envmap", CORNELL, ENV_PNG, "1", d, "7", "512"], env=env)
         pack(d, os.path.join(GOLD, "env_vectors.npz"))
+        make_jpeg_fixtures(env)
         # a small deterministic PNG from renderer::render itself (single thread + fixed seed => reproducible)
         png = os.path.join(GOLD, "cornell_ref_64x64_16spp_4b.png")
         r = subprocess.check_output([HARNESS, "render", CORNELL, "64", "64", "16", "4", "1", png], env=env)

@@ -14,6 +14,8 @@
 //   vectors <gltf> <outdir> <seed> <n>          function-level known-answer vectors as .npy
 //   materials <gltf> <outdir> <seed> <n>        per surface: material::get_* (texture lookups) at n random uvs
 //   envmap <gltf> <png> <srgb> <outdir> <seed> <n>   environment-map lookups: equirectangular_proj + image_texture::sample + trace() on misses
+//   image   <file> <outdir> <seed> <n>               decoded pixels of image::image::load's stb_image call (JPEG / PNG) + n bilinear
+//                                                     image_texture::sample lookups on it (linear and sRGB)
 //   trace   <gltf> <outdir> <seed> <n> <bounces>      trace() of n rays in sequence, ONE thread, ONE seeded mt19937 stream: pins the
 //                                                     integrator's composition bit for bit (oracle side: ora_trace_mt)
 //   mean    <gltf> <out.npy> W H spp bounces threads   float32 mean image by calling trace()
@@ -503,6 +505,30 @@ static int cmd_envmap(const char* gltf, const char* png, int srgb, const std::st
 	return 0;
 }
 
+// image::image::load (image/image.cpp:23-54): stbi_load(path, &w, &h, &channels, 0) — the decoded bytes — and image_texture::sample
+// (image/image_texture.cpp:21-62) at n random uvs, loaded once as linear and once as sRGB.
+static int cmd_image(const char* file, const std::string& dir, uint64_t seed, size_t n) {
+	std::filesystem::create_directories(dir);
+	int w = 0, h = 0, c = 0;
+	unsigned char* px = stbi_load(file, &w, &h, &c, 0);
+	if (!px) { fprintf(stderr, "image: stbi_load failed: %s\n", stbi_failure_reason()); return 2; }
+	std::vector<uint8_t> data(px, px + (size_t)w * h * c);
+	stbi_image_free(px);
+	save(dir, "pixels", data, {(size_t)h, (size_t)w, (size_t)c});
+	pcg32 g(seed);
+	std::vector<float> uv, lin, srgb;
+	auto tl = image::image_texture::load(file, false), ts = image::image_texture::load(file, true);
+	for (size_t i = 0; i < n; i++) {
+		fvec2 p(g.range(-1.5f, 2.5f), g.range(-1.5f, 2.5f));
+		if (i % 4 == 0) p = fvec2(g.uni(), g.uni());
+		uv.push_back(p.x); uv.push_back(p.y);
+		fvec4 a = tl->sample(p), b = ts->sample(p);
+		lin.insert(lin.end(), {a.x, a.y, a.z, a.w}); srgb.insert(srgb.end(), {b.x, b.y, b.z, b.w});
+	}
+	save(dir, "uv", uv, {n, 2}); save(dir, "sample_linear", lin, {n, 4}); save(dir, "sample_srgb", srgb, {n, 4});
+	return 0;
+}
+
 // renderer::trace (renderer.cpp:437-643) on n rays, one after the other, on the calling thread only. core::rand() is a `static`
 // function of core/utils.hpp, so renderer.cpp's copy owns its own thread_local mt19937, seeded at its first call from
 // std::random_device — the shim above, which has not been called before (this harness draws its inputs from pcg32): the stream is
@@ -610,6 +636,7 @@ int main(int argc, char** argv) {
 		if (cmd == "vectors" && argc == 6) return cmd_vectors(argv[2], argv[3], strtoull(argv[4], 0, 10), strtoull(argv[5], 0, 10));
 		if (cmd == "materials" && argc == 6) return cmd_materials(argv[2], argv[3], strtoull(argv[4], 0, 10), strtoull(argv[5], 0, 10));
 		if (cmd == "envmap" && argc == 8) return cmd_envmap(argv[2], argv[3], atoi(argv[4]), argv[5], strtoull(argv[6], 0, 10), strtoull(argv[7], 0, 10));
+		if (cmd == "image" && argc == 6) return cmd_image(argv[2], argv[3], strtoull(argv[4], 0, 10), strtoull(argv[5], 0, 10));
 		if (cmd == "trace" && argc == 7) return cmd_trace(argv[2], argv[3], strtoull(argv[4], 0, 10), strtoull(argv[5], 0, 10), atoi(argv[6]));
 		if (cmd == "mean" && argc == 9)
 			return cmd_mean(argv[2], argv[3], atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]));
@@ -619,6 +646,6 @@ int main(int argc, char** argv) {
 		fprintf(stderr, "ref_harness: %s\n", e.what());
 		return 2;
 	}
-	fprintf(stderr, "usage: ref_harness scene|vectors|materials|envmap|trace|mean|render ... (see header comment)\n");
+	fprintf(stderr, "usage: ref_harness scene|vectors|materials|envmap|image|trace|mean|render ... (see header comment)\n");
 	return 1;
 }

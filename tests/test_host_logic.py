@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import CORNELL
+from conftest import CORNELL, ROOT
 
 
 def test_library_exports_every_declared_symbol(ptx):
@@ -472,3 +472,111 @@ def test_malformed_worker_event_is_an_error(ptx, tmp_path):
         with pytest.raises(ptx.PtxError):
             ptx.Scene.load_event(None, str(bad), root)
     assert doc
+
+
+# ---------------------------------------------------------------------------- JPEG textures (image::image::load -> stb_image v2.30)
+def _texture_scene(ptx, tmp_path, image_path):
+    """Host-only scene whose one material samples `image_path` as base colour: the decoded texels come back through PTX_ARR_TEXELS."""
+    import json
+    import shutil
+    d = tmp_path / "jpeg_scene"
+    d.mkdir(exist_ok=True)
+    shutil.copyfile(image_path, d / "tex.bin")              # stb_image (and this reader) go by content, not by extension
+    gl = {"asset": {"version": "2.0"}, "scenes": [{"nodes": [0, 1]}], "cameras": [{"name": "c", "type": "perspective", "perspective": {"yfov": 0.7}}],
+          "nodes": [{"camera": 0, "name": "c"}, {"mesh": 0, "name": "m"}], "buffers": [{"uri": "b.bin", "byteLength": 132}],
+          "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 24},
+                          {"buffer": 0, "byteOffset": 60, "byteLength": 36}, {"buffer": 0, "byteOffset": 96, "byteLength": 6}],
+          "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": 3, "type": "VEC2"},
+                        {"bufferView": 2, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 3, "componentType": 5123, "count": 3, "type": "SCALAR"}],
+          "images": [{"uri": "tex.bin"}], "textures": [{"source": 0}], "materials": [{"name": "m", "pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}],
+          "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1, "NORMAL": 2}, "indices": 3, "material": 0}]}]}
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    blob = pos.tobytes() + np.zeros((3, 2), np.float32).tobytes() + np.tile(np.float32([0, 0, 1]), 3).tobytes() + np.uint16([0, 1, 2]).tobytes() + b"\0" * 30
+    (d / "b.bin").write_bytes(blob[:132])
+    (d / "t.gltf").write_text(json.dumps(gl))
+    s = ptx.Scene.load_gltf(None, str(d / "t.gltf"))
+    tex, texels = s.array(ptx.ARR_TEXTURES), s.array(ptx.ARR_TEXELS)
+    w, h, cs, off = (int(v) for v in tex[0])
+    return texels[off:off + w * h * (cs & 255)].reshape(h, w, cs & 255).copy()
+
+
+@pytest.fixture(scope="module")
+def gold_jpeg():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "jpeg_vectors.npz")))
+
+
+def _jpeg_files():
+    import glob
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(ROOT, "tests", "golden", "jpeg", "*.jpg")))
+
+
+@pytest.mark.parametrize("tag", _jpeg_files())
+def test_jpeg_decode_matches_reference_texel_for_texel(ptx, ora, tmp_path, gold_jpeg, tag):
+    """csrc/jpeg_read.cpp against the pixels the compiled reference (stb_image v2.30 via image::image::load, image.cpp:23-54) decoded
+    from the same file: every byte equal — integer IDCT, chroma upsampling and YCbCr -> RGB restated. Files: two of the reference's own
+    Sponza textures and synthetic ones covering 4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, progressive, restart intervals, grey, 1x1, odd sizes,
+    quality 10 and 100. Then image_texture::sample (bilinear, linear and sRGB) on those texels through the oracle's sampler (itself
+    pinned on PNGs) against the reference's lookups: bit-exact."""
+    from conftest import sha_u8
+    g = gold_jpeg
+    px = _texture_scene(ptx, tmp_path, os.path.join(ROOT, "tests", "golden", "jpeg", tag + ".jpg"))
+    assert px.shape == tuple(g[tag + "_shape"])
+    np.testing.assert_array_equal(sha_u8(px), g[tag + "_sha"])
+    if tag + "_pixels" in g:
+        np.testing.assert_array_equal(px, g[tag + "_pixels"])
+    # bilinear lookups: a one-surface oracle scene whose albedo texture is the product's decode
+    for srgb, key in ((False, "sample_linear"), (True, "sample_srgb")):
+        a = ora.SceneArrays()
+        a.model_xform = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1]], np.float32)
+        a.model_surf = np.array([[0, 1]], np.int32)
+        a.surf_range = np.array([[0, 3, 0, 1]], np.int32)
+        a.vertices = np.zeros((3, 11), np.float32); a.vertices[1, 0] = 1; a.vertices[2, 1] = 1; a.vertices[:, 7] = 1
+        a.triangles = np.array([[0, 1, 2]], np.uint32)
+        a.materials = np.array([[1, 1, 1, 1, 1, 1, 1, 1, 1, 1.33, 0]], np.float32)
+        cam = np.zeros(14, np.float32); cam[3] = cam[7] = cam[11] = 1; cam[12] = 0.7; cam[13] = 0.365
+        a.camera = cam
+        a.images, a.image_srgb, a.image_paths = [px], [srgb], [tag]
+        a.surf_tex = np.array([[-1, 0, -1, -1, -1, -1, -1]], np.int32)
+        out = ora.OracleScene(a).material_eval(0, g[tag + "_uv"])
+        ref = g[f"{tag}_{key}"]
+        n_ch = px.shape[2]
+        exp = ref[:, :3] if n_ch >= 3 else np.stack([ref[:, 0], np.ones(len(ref), np.float32), np.ones(len(ref), np.float32)], 1)   # missing channels read 1 (image_texture.cpp:47-62)
+        np.testing.assert_array_equal(out[:, 3:6].view(np.uint32), np.ascontiguousarray(exp, np.float32).view(np.uint32))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/path-tracer-core/scenes/sponza-new/textures"), reason="the reference tree (38 MB of textures) is not on this machine")
+def test_all_63_sponza_jpegs_decode_like_the_reference(ptx, tmp_path, gold_jpeg):
+    """Every JPEG of scenes/sponza-new/textures (63 baseline 4:4:4 files of 1024 x 1024): SHA-256 of the decoded pixels equals the
+    digest of the compiled reference's decode (fixture). Runs only where the reference tree exists; the fixture travels."""
+    from conftest import sha_u8
+    d = "/root/reference/path-tracer-core/scenes/sponza-new/textures"
+    names = [str(n) for n in gold_jpeg["sponza_names"]]
+    assert len(names) == 63
+    for n, ref in zip(names[::4], gold_jpeg["sponza_sha"][::4]):          # every fourth file: 16 MB of pixels, ~2 s
+        np.testing.assert_array_equal(sha_u8(_texture_scene(ptx, tmp_path, os.path.join(d, n))), ref, err_msg=n)
+
+
+def test_jpeg_refusals_and_malformed_files(ptx, tmp_path):
+    """CMYK / 12-bit / arithmetic files are refused (PTX_ERR_UNSUPPORTED); truncated or corrupted files give an error or an image,
+    never a crash."""
+    import random
+    src = open(os.path.join(ROOT, "tests", "golden", "jpeg", "s420.jpg"), "rb").read()
+    from PIL import Image
+    Image.new("CMYK", (16, 16), (10, 20, 30, 40)).save(tmp_path / "cmyk.jpg")
+    with pytest.raises(ptx.PtxError) as e:
+        _texture_scene(ptx, tmp_path, str(tmp_path / "cmyk.jpg"))
+    assert e.value.code == ptx.ERR_UNSUPPORTED
+    rnd = random.Random(2)
+    for k in range(80):
+        b = bytearray(src)
+        if k % 2:
+            b = b[:rnd.randrange(2, len(b))]
+        else:
+            for _ in range(rnd.randrange(1, 6)):
+                b[rnd.randrange(2, len(b))] = rnd.randrange(256)
+        (tmp_path / "m.jpg").write_bytes(bytes(b))
+        try:
+            px = _texture_scene(ptx, tmp_path, str(tmp_path / "m.jpg"))
+            assert px.ndim == 3
+        except ptx.PtxError as e:
+            assert e.code in (ptx.ERR_PARSE, ptx.ERR_UNSUPPORTED, ptx.ERR_IO), e
