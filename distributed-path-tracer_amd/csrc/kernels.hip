@@ -94,6 +94,8 @@ struct Geom {
 	// spare word — a leaf's records are contiguous and the refs -> record indirection (a second dependent fetch from
 	// L2/HBM per triangle) disappears. false (LDS kernels): one record per triangle, reached through `refs`.
 	bool leaf_ordered;
+	// true (the global-memory copy): a branch node's two children (adjacent, 16 bytes) are requested as soon as the parent arrives
+	bool pair;
 };
 // Both copies a kernel may traverse (kernels.hpp: MODE_GLOBAL / MODE_LDS / MODE_HYBRID); in MODE_HYBRID the branch between
 // them is wave-uniform (the surface index is).
@@ -221,7 +223,11 @@ DEV bool mesh_traverse(const Geom& g, uint32_t root, float nr, float fr, V3 o, V
 #else
 			constexpr bool pair_fetch = false;
 #endif
-			if (pair_fetch && g.leaf_ordered) { kid0 = g.nodes[nd.y >> 4]; kid1 = g.nodes[(nd.y >> 4) + 1u]; }
+#ifdef PTX_LDS_PAIR_FETCH
+			if (pair_fetch) { kid0 = g.nodes[nd.y >> 4]; kid1 = g.nodes[(nd.y >> 4) + 1u]; }
+#else
+			if (pair_fetch && g.pair) { kid0 = g.nodes[nd.y >> 4]; kid1 = g.nodes[(nd.y >> 4) + 1u]; }
+#endif
 			float split = __uint_as_float(nd.x);
 			float oa = sel3(o, axis), da = sel3(d, axis);
 			float split_dist = (split - oa) / da;
@@ -245,13 +251,34 @@ DEV bool mesh_traverse(const Geom& g, uint32_t root, float nr, float fr, V3 o, V
 			}
 			if (!has_next) { valid = false; break; }
 			node = next;
-			nd = (pair_fetch && g.leaf_ordered) ? (next == li ? kid0 : kid1) : g.nodes[node];
+#ifdef PTX_LDS_PAIR_FETCH
+			nd = pair_fetch ? (next == li ? kid0 : kid1) : g.nodes[node];
+#else
+			nd = (pair_fetch && g.pair) ? (next == li ? kid0 : kid1) : g.nodes[node];
+#endif
 		}
 		if (!valid) continue;
 		// leaf: nearest triangle with t <= max_dist; ties keep the first (mesh.cpp:381-389)
 		uint32_t first_ref = nd.x, count = nd.y >> 2;
 		float best_t = -1.0f, bb1 = 0, bb2 = 0;
 		uint32_t best_tri = 0;
+#ifdef PTX_LEAF_PIPELINE
+		// software-pipelined: the record of triangle i + 1 (and, in LDS, the reference that leads to it) is requested before the solve of
+		// triangle i starts, so its LDS / L2 latency runs under ~45 VALU instructions instead of in front of them
+		uint32_t slot_n = g.leaf_ordered ? first_ref : g.refs[first_ref];
+		float4 n0 = g.tris[3 * slot_n], n1 = g.tris[3 * slot_n + 1], n2 = g.tris[3 * slot_n + 2];
+		for (uint32_t i = 0; i < count; i++) {
+			PROF(PB + 3);
+			const float4 r0 = n0, r1 = n1, r2 = n2;
+			const uint32_t nx = i + 1 < count ? i + 1 : i;   // the last trip re-requests its own record: no branch, nothing out of bounds
+			slot_n = g.leaf_ordered ? first_ref + nx : g.refs[first_ref + nx];
+			n0 = g.tris[3 * slot_n]; n1 = g.tris[3 * slot_n + 1]; n2 = g.tris[3 * slot_n + 2];
+			const uint32_t ti = __float_as_uint(r2.z);   // global triangle id, carried by every record
+			float be, ga;
+			const float t = tri_test_pk(r0, r1, make_float2(r2.x, r2.y), pr, be, ga);
+			if (t >= 0 && t <= max_dist && (t < best_t || !(best_t >= 0))) { best_t = t; bb1 = be; bb2 = ga; best_tri = ti; }
+		}
+#else
 		for (uint32_t i = 0; i < count; i++) {
 			PROF(PB + 3);
 			const uint32_t slot = g.leaf_ordered ? first_ref + i : g.refs[first_ref + i];
@@ -261,6 +288,7 @@ DEV bool mesh_traverse(const Geom& g, uint32_t root, float nr, float fr, V3 o, V
 			const float t = tri_test_pk(r0, r1, make_float2(r2.x, r2.y), pr, be, ga);
 			if (t >= 0 && t <= max_dist && (t < best_t || !(best_t >= 0))) { best_t = t; bb1 = be; bb2 = ga; best_tri = ti; }
 		}
+#endif
 		if (!(best_t >= 0)) continue;
 		out.t = best_t; out.b1 = bb1; out.b2 = bb2; out.tri = best_tri;
 		return true;
@@ -753,7 +781,7 @@ struct Staged { Geoms g; const ShadeRec* shade; };
 
 template <int MODE>
 DEV Staged stage_geometry(const DevScene& S, unsigned char* smem) {
-	const Geom glb = {S.nodes, nullptr, S.tri_isect, true};   // tri_isect: leaf-ordered records of ALL surfaces (upload_scene)
+	const Geom glb = {S.nodes, S.refs, S.tri_isect, S.glb_leaf_ordered != 0, true};   // tri_isect: records of ALL surfaces, per leaf reference or per triangle (upload_scene)
 	if constexpr (MODE == MODE_GLOBAL) return {{glb, glb}, S.shade};
 	else {
 		// the resident arrays (all surfaces in MODE_LDS, the ones that fit in MODE_HYBRID):
@@ -772,12 +800,47 @@ DEV Staged stage_geometry(const DevScene& S, unsigned char* smem) {
 		for (uint32_t i = threadIdx.x; i < n_node16; i += blockDim.x) d_n[i] = src_n[i];
 		for (uint32_t i = threadIdx.x; i < n_ref16; i += blockDim.x) d_r[i] = src_r[i];
 		__syncthreads();
-		const Geom lds = {reinterpret_cast<const uint2*>(d_n), reinterpret_cast<const uint32_t*>(d_r), reinterpret_cast<const float4*>(dst), false};
+		const Geom lds = {reinterpret_cast<const uint2*>(d_n), reinterpret_cast<const uint32_t*>(d_r), reinterpret_cast<const float4*>(dst), false, false};
 		return {{lds, glb}, reinterpret_cast<const ShadeRec*>(d_s)};
 	}
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
+
+// Wave-private stream arrays. Each entry is written once and read once or twice a whole sweep later, by which time the chip's
+// 16 K waves have pushed ~1.6 GB through the caches: with PTX_NT_STREAMS the accesses carry the non-temporal hint, so that they do
+// not displace the scene's nodes and triangle records from L2 / Infinity Cache (measurement switch).
+#ifdef PTX_NT_STREAMS
+typedef float f4n __attribute__((ext_vector_type(4)));
+typedef float f2n __attribute__((ext_vector_type(2)));
+struct Q4Ref {
+	float4* p;
+	DEV operator float4() const { const f4n v = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+	DEV void operator=(float4 v) const { const f4n w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<f4n*>(p)); }
+	DEV void operator=(const Q4Ref& o) const { *this = (float4)o; }
+};
+struct Q4 {
+	float4* p;
+	DEV Q4Ref operator[](size_t i) const { return {p + i}; }
+	DEV Q4 operator+(size_t k) const { return {p + k}; }
+};
+struct Q2Ref {
+	float2* p;
+	DEV operator float2() const { const f2n v = __builtin_nontemporal_load(reinterpret_cast<const f2n*>(p)); return make_float2(v.x, v.y); }
+	DEV void operator=(float2 v) const { const f2n w = {v.x, v.y}; __builtin_nontemporal_store(w, reinterpret_cast<f2n*>(p)); }
+};
+struct Q2 {
+	float2* p;
+	DEV Q2Ref operator[](size_t i) const { return {p + i}; }
+};
+DEV float4* raw(Q4 q) { return q.p; }
+DEV float2* raw(Q2 q) { return q.p; }
+#else
+typedef float4* Q4;
+typedef float2* Q2;
+DEV float4* raw(Q4 q) { return q; }
+DEV float2* raw(Q2 q) { return q; }
+#endif
 
 // ------------------------------------------------------------------------------------ integrator kernel
 // One launch = `P.n_paths` camera paths (P.pass_spp samples of every tile pixel), all bounces.
@@ -794,11 +857,11 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave_slot = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	// wave-private streams: 2 ray buffers x 4 float4 arrays x kChunk entries, then 1 hit array
-	float4* qbase = B.queues + (size_t)wave_slot * B.queue_stride;
-	float4* hbuf = qbase + 2u * 4u * kChunk;
-	float2* hdist = reinterpret_cast<float2*>(hbuf + kChunk);               // [kChunk] (world distance, local t) of the current best hit (deferral)
-	float4* sreq = hbuf + kChunk + kChunk / 2u;                              // [3][kChunk] shadow requests: (origin, target) (dir, kind) (x, path id)
-	float4* lists = sreq + 3u * kChunk;                                      // [units][2][kListCap]: (local origin, ray index), (local dir, -); units = models, or surfaces (SURF)
+	const Q4 qbase = Q4{B.queues + (size_t)wave_slot * B.queue_stride};
+	const Q4 hbuf = qbase + 2u * 4u * kChunk;
+	const Q2 hdist = Q2{reinterpret_cast<float2*>(raw(hbuf) + kChunk)};               // [kChunk] (world distance, local t) of the current best hit (deferral)
+	const Q4 sreq = hbuf + (kChunk + kChunk / 2u);                              // [3][kChunk] shadow requests: (origin, target) (dir, kind) (x, path id)
+	const Q4 lists = sreq + 3u * kChunk;                                      // [units][2][kListCap]: (local origin, ray index), (local dir, -); units = models, or surfaces (SURF)
 	const Spill spill{B.spill + (size_t)wave_slot * (kSpillStack * 64) + lane};
 	uint32_t rays = 0;
 #ifdef PTX_PROF
@@ -833,8 +896,8 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 		// One step = every live path of the chunk advances by one stream entry: a scatter (depth + 1) or, with ALPHA, a
 		// pass-through (same depth, pass + 1). Without pass-through all paths of a step have depth == step.
 		for (uint32_t step = 0; P.bounces > 0 && n_in > 0; step++) {
-			float4* qin = qbase + (size_t)(step & 1u) * (4u * kChunk);
-			float4* qout = qbase + (size_t)((step + 1u) & 1u) * (4u * kChunk);
+			const Q4 qin = qbase + (size_t)(step & 1u) * (4u * kChunk);
+			const Q4 qout = qbase + (size_t)((step + 1u) & 1u) * (4u * kChunk);
 
 			// ---------------- EXTEND
 			// lists live in the unused part of the wave's stream area: hdist (kChunk words) + n_models lists
@@ -906,7 +969,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 								if (ent) {
 									PROF(14);
 									const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-									float4* L0 = lists + (size_t)u * 2u * kListCap;
+									const Q4 L0 = lists + (size_t)u * 2u * kListCap;
 									L0[len + r] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(i));
 									L0[kListCap + len + r] = make_float4(ld.x, ld.y, ld.z, 0.f);
 								}
@@ -951,7 +1014,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 								PROF(14);
 								const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
 								// the deferred sweep gets the LOCAL ray: no gather of the stream entry, no second transform
-								float4* L0 = lists + (size_t)m * 2u * kListCap;
+								const Q4 L0 = lists + (size_t)m * 2u * kListCap;
 								L0[len + r] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(i));
 								L0[kListCap + len + r] = make_float4(ld.x, ld.y, ld.z, 0.f);
 							}
@@ -959,7 +1022,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 						}
 					}
 				}
-				if (active) { hbuf[i] = make_float4(__int_as_float(h.surface), __uint_as_float(h.tri), h.b1, h.b2); if (defer && !SURF) hdist[i].x = h.dist; }
+				if (active) { hbuf[i] = make_float4(__int_as_float(h.surface), __uint_as_float(h.tri), h.b1, h.b2); if (defer && !SURF) raw(hdist)[i].x = h.dist; }
 			}
 			if (defer) {
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -972,7 +1035,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 						const SurfaceRec& sf = S.surfaces[u];
 						const int m = (int)sf.model;
 						const ModelRec& M = S.models[m];
-						const float4* L0 = lists + (size_t)u * 2u * kListCap;
+						const Q4 L0 = lists + (size_t)u * 2u * kListCap;
 						for (uint32_t base = 0; base < len; base += 64) {
 							if (base + lane < len) {
 								PROF(8);
@@ -1003,14 +1066,14 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 					const uint32_t len = __builtin_amdgcn_readlane(list_len, m);
 					if (len == 0) continue;
 					const ModelRec& M = S.models[m];
-					const float4* L0 = lists + (size_t)m * 2u * kListCap;
+					const Q4 L0 = lists + (size_t)m * 2u * kListCap;
 					for (uint32_t base = 0; base < len; base += 64) {
 						if (base + lane < len) {
 							PROF(8);
 							const float4 e0 = L0[base + lane], e1 = L0[kListCap + base + lane];
 							const uint32_t i = __float_as_uint(e0.w);
-							const float bd = hdist[i].x;                     // current best of this ray: issued before the traversal
-							const int bs = __float_as_int(hbuf[i].x);
+							const float bd = raw(hdist)[i].x;                     // current best of this ray: issued before the traversal
+							const int bs = __float_as_int(raw(hbuf)[i].x);
 							const V3 lo = mk(e0.x, e0.y, e0.z), ld = mk(e1.x, e1.y, e1.z);
 							const V3 inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
 							float wd, b1, b2; int surf; uint32_t tri;
@@ -1018,7 +1081,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 							    model_traverse<MODE, 10>(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill PROF_PASS) &&
 							    (wd < bd || !(bd >= 0) || (wd == bd && surf < bs))) {
 								hbuf[i] = make_float4(__int_as_float(surf), __uint_as_float(tri), b1, b2);
-								hdist[i].x = wd;
+								raw(hdist)[i].x = wd;
 							}
 						}
 					}
@@ -1133,7 +1196,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 									const uint32_t len = __builtin_amdgcn_readlane(list_len, u);
 									if (ent) {
 										const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-										float4* L0 = lists + (size_t)u * 2u * kListCap;
+										const Q4 L0 = lists + (size_t)u * 2u * kListCap;
 										L0[len + r] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(j));
 										L0[kListCap + len + r] = make_float4(ld.x, ld.y, ld.z, 0.f);
 									}
@@ -1141,7 +1204,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 								}
 							}
 						}
-						if (active && occ) { uint32_t* kw = reinterpret_cast<uint32_t*>(sreq + kChunk + j) + 3; *kw = *kw | kOccluded; }
+						if (active && occ) { uint32_t* kw = reinterpret_cast<uint32_t*>(raw(sreq) + kChunk + j) + 3; *kw = *kw | kOccluded; }
 					}
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1150,12 +1213,12 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 						if (len == 0) continue;
 						const SurfaceRec& sf = S.surfaces[u];
 						const ModelRec& M = S.models[sf.model];
-						const float4* L0 = lists + (size_t)u * 2u * kListCap;
+						const Q4 L0 = lists + (size_t)u * 2u * kListCap;
 						for (uint32_t base = 0; base < len; base += 64) {
 							if (base + lane < len) {
 								const float4 e0 = L0[base + lane], e1 = L0[kListCap + base + lane];
 								const uint32_t j = __float_as_uint(e0.w);
-								uint32_t* kw = reinterpret_cast<uint32_t*>(sreq + kChunk + j) + 3;
+								uint32_t* kw = reinterpret_cast<uint32_t*>(raw(sreq) + kChunk + j) + 3;
 								if (!(*kw & kOccluded)) {
 									const V3 lo = mk(e0.x, e0.y, e0.z), ld = mk(e1.x, e1.y, e1.z);
 									const V3 inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
@@ -1186,7 +1249,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 									B.sample_rad[id] = make_float4(v.x + x.x, v.y + x.y, v.z + x.z, v.w);
 								} else {
 									float4 q2 = qout[2 * kChunk + target];
-									float* lz = reinterpret_cast<float*>(qout + 3 * kChunk + target);
+									float* lz = reinterpret_cast<float*>(raw(qout) + 3 * kChunk + target);
 									qout[2 * kChunk + target] = make_float4(q2.x, q2.y, q2.z + x.x, q2.w + x.y);
 									*lz = *lz + x.z;
 								}

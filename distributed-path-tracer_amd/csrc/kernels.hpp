@@ -55,6 +55,7 @@ struct DevScene {
 	const TexRec* tex;       // textures
 	const uint8_t* texels;   // 8-bit texel bytes of all textures
 	const float* srgb_lut;   // [256] pow(b / 255, 2.2)
+	uint32_t glb_leaf_ordered; // layout of tri_isect: 1 = one record per leaf reference (leaf order), 0 = one per triangle (reached through refs)
 	uint32_t any_texture;
 	int32_t env_tex;         // environment map (renderer::environment): texture index or -1
 	const uint32_t* model_space; // per model

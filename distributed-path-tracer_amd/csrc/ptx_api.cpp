@@ -70,7 +70,8 @@ void srgb_thresholds(float thr[256]) {
 	}
 }
 
-constexpr size_t kLdsBudget = 160 * 1024;  // per-CU LDS on gfx950; one workgroup may take all of it
+constexpr size_t kLdsBudget = 160 * 1024;
+constexpr size_t kLeafOrderMaxBytes = (size_t)1 << 40;   // set by measurement (DESIGN.md "Residency modes")  // per-CU LDS on gfx950; one workgroup may take all of it
 
 }  // namespace
 
@@ -94,6 +95,7 @@ struct ptx_scene {
 	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr, d_isect, d_shade, d_tex, d_texels, d_lut, d_spaces, d_model_space;
 	DevBuf d_res_nodes, d_res_refs, d_res_tris;
 	DevScene dev{};
+	bool leaf_ordered = true; // global-memory copy of the triangle records: per leaf reference (true) or per triangle (false)
 	int mode = MODE_GLOBAL;   // where the traversal arrays live: MODE_GLOBAL / MODE_LDS / MODE_HYBRID (kernels.hip)
 	size_t lds_bytes = 0;     // dynamic LDS of the kernels (resident arrays + shade records)
 };
@@ -111,6 +113,11 @@ void decide_mode(ptx_scene* sc) {
 	else sc->mode = getenv("PTX_NO_HYBRID") ? MODE_GLOBAL : MODE_HYBRID;
 	if (sc->mode == MODE_GLOBAL) for (auto& sr : h.surfaces) sr.lds_root = 0xFFFFFFFFu;
 	sc->lds_bytes = sc->mode == MODE_GLOBAL ? 0 : h.res_bytes;
+	// Leaf-ordered records duplicate a triangle once per leaf that references it (12x on deep SAH trees). While the duplicated array
+	// stays cache-resident that costs nothing and saves a dependent fetch per test; once it outgrows the caches (the Infinity Cache
+	// also holds the ray streams) the smaller per-triangle layout wins. PTX_LEAF_ORDER=0/1 overrides (measurement).
+	sc->leaf_ordered = h.kd_refs.size() * 48 <= kLeafOrderMaxBytes;
+	if (const char* e = getenv("PTX_LEAF_ORDER")) sc->leaf_ordered = e[0] != '0';
 }
 
 int upload_scene(ptx_scene* sc) {
@@ -132,12 +139,18 @@ int upload_scene(ptx_scene* sc) {
 	decide_mode(sc);   // sets SurfaceRec::lds_root: before the surface table goes up
 	HIP_TRY(up(sc->d_surfaces, h.surfaces.data(), h.surfaces.size() * sizeof(SurfaceRec), h.surfaces.size() * sizeof(SurfaceRec)));
 	if (sc->mode != MODE_LDS) {
-		// surfaces that stay in L2/HBM: one record per leaf reference, in leaf order, so that a leaf's triangles are one
-		// contiguous run and the reference -> record indirection is gone (Geom::leaf_ordered)
-		std::vector<TriIsect> leaf(h.kd_refs.size());
-		for (size_t r = 0; r < leaf.size(); r++) leaf[r] = h.tri_isect[h.kd_refs[r]];
-		HIP_TRY(up(sc->d_isect, leaf.data(), leaf.size() * 48, leaf.size() * 48));
-		HIP_TRY(hipStreamSynchronize(c->stream));   // `leaf` is about to go out of scope
+		if (sc->leaf_ordered) {
+			// surfaces that stay in L2/HBM: one record per leaf reference, in leaf order, so that a leaf's triangles are one
+			// contiguous run and the reference -> record indirection is gone (Geom::leaf_ordered)
+			std::vector<TriIsect> leaf(h.kd_refs.size());
+			for (size_t r = 0; r < leaf.size(); r++) leaf[r] = h.tri_isect[h.kd_refs[r]];
+			HIP_TRY(up(sc->d_isect, leaf.data(), leaf.size() * 48, leaf.size() * 48));
+			HIP_TRY(hipStreamSynchronize(c->stream));   // `leaf` is about to go out of scope
+		} else {
+			// one record per TRIANGLE, reached through the leaf references: an extra dependent fetch per test, but a working set
+			// (nodes + refs + records) several times smaller when leaves share many triangles
+			HIP_TRY(up(sc->d_isect, h.tri_isect.data(), h.tri_isect.size() * 48, h.tri_isect.size() * 48));
+		}
 	}
 	if (sc->mode != MODE_GLOBAL) {
 		HIP_TRY(up(sc->d_res_nodes, h.res_nodes.data(), h.res_nodes.size() * 8, pad16(h.res_nodes.size() * 8)));
@@ -176,6 +189,7 @@ int upload_scene(ptx_scene* sc) {
 	d.tex = (const TexRec*)sc->d_tex.p;
 	d.texels = (const uint8_t*)sc->d_texels.p;
 	d.srgb_lut = (const float*)sc->d_lut.p;
+	d.glb_leaf_ordered = sc->leaf_ordered ? 1u : 0u;
 	d.any_texture = (h.any_texture || h.env_tex >= 0) ? 1u : 0u;   // the TEX kernels also carry the environment lookup
 	d.env_tex = h.env_tex;
 	d.model_space = (const uint32_t*)sc->d_model_space.p;
