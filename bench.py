@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--shard", choices=("samples", "tiles"), default="samples",
                     help="how ONE frame is split over N ranks: contiguous shares of the sample indices (default) or interleaved 64x64 tiles")
+    ap.add_argument("--spp-per-pass", type=int, default=0, help="samples of every pixel per kernel launch (0 = the library's default)")
     ap.add_argument("--weak", action="store_true", help="weak scaling instead: every rank traces --spp samples of its own")
     args = ap.parse_args()
 
@@ -167,11 +168,11 @@ def main():
         torch.cuda.synchronize()
         # this rank's share -> ptx_render -> (N > 1) RCCL sum-reduce of the framebuffer onto rank 0
         if mode == "weak":
-            st = mg.render_sharded(scene, W, H, spp, BOUNCES, accum, rank, world, want_stats=True)
+            st = mg.render_sharded(scene, W, H, spp, BOUNCES, accum, rank, world, want_stats=True, spp_per_pass=args.spp_per_pass)
         elif mode == "tiles":
-            st = mg.render_tiles(scene, W, H, spp, BOUNCES, accum, rank, world, want_stats=True)
+            st = mg.render_tiles(scene, W, H, spp, BOUNCES, accum, rank, world, want_stats=True, spp_per_pass=args.spp_per_pass)
         else:
-            st = mg.render_samples(scene, W, H, spp, BOUNCES, accum, rank, world, want_stats=True)
+            st = mg.render_samples(scene, W, H, spp, BOUNCES, accum, rank, world, want_stats=True, spp_per_pass=args.spp_per_pass)
         if collect is not None:
             collect.append(st)
 

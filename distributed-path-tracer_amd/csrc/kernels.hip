@@ -262,23 +262,8 @@ DEV bool mesh_traverse(const Geom& g, uint32_t root, float nr, float fr, V3 o, V
 		uint32_t first_ref = nd.x, count = nd.y >> 2;
 		float best_t = -1.0f, bb1 = 0, bb2 = 0;
 		uint32_t best_tri = 0;
-#ifdef PTX_LEAF_PIPELINE
-		// software-pipelined: the record of triangle i + 1 (and, in LDS, the reference that leads to it) is requested before the solve of
-		// triangle i starts, so its LDS / L2 latency runs under ~45 VALU instructions instead of in front of them
-		uint32_t slot_n = g.leaf_ordered ? first_ref : g.refs[first_ref];
-		float4 n0 = g.tris[3 * slot_n], n1 = g.tris[3 * slot_n + 1], n2 = g.tris[3 * slot_n + 2];
-		for (uint32_t i = 0; i < count; i++) {
-			PROF(PB + 3);
-			const float4 r0 = n0, r1 = n1, r2 = n2;
-			const uint32_t nx = i + 1 < count ? i + 1 : i;   // the last trip re-requests its own record: no branch, nothing out of bounds
-			slot_n = g.leaf_ordered ? first_ref + nx : g.refs[first_ref + nx];
-			n0 = g.tris[3 * slot_n]; n1 = g.tris[3 * slot_n + 1]; n2 = g.tris[3 * slot_n + 2];
-			const uint32_t ti = __float_as_uint(r2.z);   // global triangle id, carried by every record
-			float be, ga;
-			const float t = tri_test_pk(r0, r1, make_float2(r2.x, r2.y), pr, be, ga);
-			if (t >= 0 && t <= max_dist && (t < best_t || !(best_t >= 0))) { best_t = t; bb1 = be; bb2 = ga; best_tri = ti; }
-		}
-#else
+		// (a software-pipelined form of this loop — triangle i + 1's reference and record requested before triangle i's solve — was
+		// measured: -2.7 % on Cornell, +2 % on jack-of-blades; the extra registers cost more than the latency 4 waves already hide)
 		for (uint32_t i = 0; i < count; i++) {
 			PROF(PB + 3);
 			const uint32_t slot = g.leaf_ordered ? first_ref + i : g.refs[first_ref + i];
@@ -288,7 +273,6 @@ DEV bool mesh_traverse(const Geom& g, uint32_t root, float nr, float fr, V3 o, V
 			const float t = tri_test_pk(r0, r1, make_float2(r2.x, r2.y), pr, be, ga);
 			if (t >= 0 && t <= max_dist && (t < best_t || !(best_t >= 0))) { best_t = t; bb1 = be; bb2 = ga; best_tri = ti; }
 		}
-#endif
 		if (!(best_t >= 0)) continue;
 		out.t = best_t; out.b1 = bb1; out.b2 = bb2; out.tri = best_tri;
 		return true;
@@ -808,9 +792,10 @@ DEV Staged stage_geometry(const DevScene& S, unsigned char* smem) {
 extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 
 // Wave-private stream arrays. Each entry is written once and read once or twice a whole sweep later, by which time the chip's
-// 16 K waves have pushed ~1.6 GB through the caches: with PTX_NT_STREAMS the accesses carry the non-temporal hint, so that they do
-// not displace the scene's nodes and triangle records from L2 / Infinity Cache (measurement switch).
-#ifdef PTX_NT_STREAMS
+// 16 K waves have pushed ~1.6 GB through the caches: the accesses carry the non-temporal hint, so that they do
+// not displace the scene's nodes and triangle records from L2 / Infinity Cache. Same-box A/B: +1.5 % on Cornell 1080p, neutral to
+// +2 % on the large-mesh scenes, images bit-identical (profiles/round2_ab_nt_streams.txt); -DPTX_PLAIN_STREAMS builds the plain form.
+#ifndef PTX_PLAIN_STREAMS
 typedef float f4n __attribute__((ext_vector_type(4)));
 typedef float f2n __attribute__((ext_vector_type(2)));
 struct Q4Ref {

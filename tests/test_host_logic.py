@@ -254,8 +254,37 @@ def test_png_reader_against_pil(ptx, tmp_path):
     blob = pos.tobytes() + np.zeros((3, 2), np.float32).tobytes() + np.tile(np.float32([0, 0, 1]), 3).tobytes() + np.uint16([0, 1, 2]).tobytes() + b"\0" * 30
     (tmp_path / "b.bin").write_bytes(blob[:132])
     names = sorted(imgs)
-    for i, n in enumerate(names):
+    for n in names:
         imgs[n].save(tmp_path / f"{n}.png", optimize=True)
+    # Adam7-interlaced files (Pillow cannot write them): built by hand from the same pixels, filter type 0, for 8-bit RGBA, 8-bit grey
+    # with a width that leaves some passes empty, and 4-bit grey (sub-byte rows per pass)
+    import struct
+    import zlib
+
+    def adam7_png(path, arr, depth, ctype):
+        h, w = arr.shape[:2]
+        ch = 1 if arr.ndim == 2 else arr.shape[2]
+        raw = b""
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = arr[y0::dy, x0::dx]
+            if sub.size == 0:
+                continue
+            for row in sub.reshape(sub.shape[0], -1):
+                if depth == 8:
+                    raw += b"\0" + row.astype(np.uint8).tobytes()
+                else:                                           # 4-bit: two samples per byte, MSB first
+                    v = list(row.astype(np.uint8)) + [0]
+                    raw += b"\0" + bytes((v[k] << 4) | v[k + 1] for k in range(0, len(row), 2))
+
+        def chunk(t, d):
+            return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+        path.write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1)) +
+                         chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    adam7_png(tmp_path / "i_rgba.png", base, 8, 6)
+    adam7_png(tmp_path / "i_l_narrow.png", base[:5, :3, 1].copy(), 8, 0)
+    adam7_png(tmp_path / "i_l4.png", (base[:, :, 1] >> 4).copy(), 4, 0)
+    names += ["i_rgba", "i_l_narrow", "i_l4"]
+    for i, n in enumerate(names):
         gl["images"].append({"uri": f"{n}.png"}); gl["textures"].append({"source": i})
         gl["materials"].append({"name": n, "pbrMetallicRoughness": {"baseColorTexture": {"index": i}}})
         gl["meshes"][0]["primitives"].append({"attributes": {"POSITION": 0, "TEXCOORD_0": 1, "NORMAL": 2}, "indices": 3, "material": i})
