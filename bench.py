@@ -39,6 +39,7 @@ W, H, SPP, BOUNCES = 1920, 1080, 256, 8
 # /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # HBM3E spec peak
 N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs
+MAX_CLOCK_GHZ = 2.4            # "Max clock 2400 MHz" (chip-level parameters)
 # SURVEY.md §8(d), HBM part only: ray / hit / path-state streams 188 B per ray + 192 B of hit attributes per hit; the KD nodes and
 # triangle records (8*3.44 + 40*11.82 = 500 B per ray on the Cornell trees) are served by LDS in this kernel and never reach HBM
 B_STREAM, B_ATTR = 188.0, 192.0
@@ -222,13 +223,13 @@ def main():
                "achieved": round(hbm_alg / (kernel_ms * 1e-3) / 1e9, 1)}
         hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBS, 4)
         if prof:
-            clock_ghz = prof["shader_clock_ghz"]
             valu_per_ray = prof["valu_insts_per_ray"]
             achieved = valu_per_ray * rays_per_launch / (kernel_ms * 1e-3) / 1e9          # G wave-instructions / s
-            peak = N_SIMD * clock_ghz / 2.0
+            peak = N_SIMD * MAX_CLOCK_GHZ / 2.0                                            # at the chip's maximum clock: the fraction can only be understated
             traffic = prof["hbm_bytes_per_ray"] * rays_per_launch
             roof.update({"achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "G wave64-VALU-instr/s", "frac": round(achieved / peak, 4),
-                         "peak_note": f"{N_SIMD} SIMDs x {clock_ghz} GHz / 2 cycles per instruction",
+                         "peak_note": f"{N_SIMD} SIMDs x {MAX_CLOCK_GHZ} GHz (max clock) / 2 cycles per wave64 instruction; in cycles of the profiled launch "
+                                      f"({prof.get('shader_clock_ghz')} GHz under the profiler) the same ratio is {prof.get('valu_issue_frac_2cycle')}",
                          "busy_frac_mix_weighted": prof.get("valu_busy_frac_mix_weighted"),
                          "lane_utilisation": prof.get("lane_utilisation"),
                          "traffic": round(traffic), "traffic_source": prof["file"], "counters_stale": prof["stale"]})
