@@ -27,7 +27,7 @@ OK, ERR_INVALID, ERR_IO, ERR_PARSE, ERR_NO_CAMERA, ERR_NO_DEVICE, ERR_HIP, ERR_U
 NO_SUN_LIGHT = 0xFFFFFFFF  # core::renderer::no_sun_light, renderer.hpp:19
 
 (ARR_MODEL_XFORM, ARR_MODEL_AABB, ARR_MODEL_SURF, ARR_SURF_RANGE, ARR_MESH_AABB, ARR_VERTICES, ARR_TRIANGLES,
- ARR_MATERIALS, ARR_KD_NODES, ARR_KD_REFS, ARR_CAMERA, ARR_SUN, ARR_MODEL_NAMES, ARR_TEXTURES, ARR_TEXELS, ARR_SURF_TEX) = range(16)
+ ARR_MATERIALS, ARR_KD_NODES, ARR_KD_REFS, ARR_CAMERA, ARR_SUN, ARR_MODEL_NAMES, ARR_TEXTURES, ARR_TEXELS, ARR_SURF_TEX, ARR_TEXELS_F32) = range(17)
 
 
 class PtxError(RuntimeError):
@@ -230,7 +230,7 @@ _ARR_DTYPE = {ARR_MODEL_XFORM: (np.float32, 12), ARR_MODEL_AABB: (np.float32, 6)
               ARR_SURF_RANGE: (np.int32, 8), ARR_MESH_AABB: (np.float32, 6), ARR_VERTICES: (np.float32, 11),
               ARR_TRIANGLES: (np.uint32, 3), ARR_MATERIALS: (np.float32, 11), ARR_KD_NODES: (np.uint32, 2),
               ARR_KD_REFS: (np.uint32, 1), ARR_CAMERA: (np.float32, 1), ARR_SUN: (np.float32, 1),
-              ARR_TEXTURES: (np.uint32, 4), ARR_TEXELS: (np.uint8, 1), ARR_SURF_TEX: (np.int32, 7)}
+              ARR_TEXTURES: (np.uint32, 4), ARR_TEXELS: (np.uint8, 1), ARR_SURF_TEX: (np.int32, 7), ARR_TEXELS_F32: (np.float32, 1)}
 
 
 class Scene:

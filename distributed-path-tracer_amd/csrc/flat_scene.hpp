@@ -78,7 +78,9 @@ static_assert(sizeof(MaterialRec) == 80, "MaterialRec layout");
 
 // ---- texture: 8-bit texels exactly as the reference keeps them (image::image::data, image.cpp:124-141); the sRGB
 // decode pow(v/255, 2.2) of colour channels is a 256-entry table computed on the host with the same libm call.
-struct TexRec { uint32_t w, h, c_srgb /* channels | srgb << 8 */, offset /* first byte in the texel array */; };
+// A Radiance .hdr image keeps its floats (image::read returns them unscaled): c_srgb bit 16, offset counts floats in `texels_f`.
+struct TexRec { uint32_t w, h, c_srgb /* channels | srgb << 8 | float texels << 16 */, offset /* first byte in the texel array (first float for float texels) */; };
+constexpr uint32_t kTexSrgb = 1u << 8, kTexFloat = 1u << 16;
 
 // ---- everything the SHADING phase needs about the surface that was hit, gathered per surface so that a
 // divergent lookup is 9 aligned 16-byte reads from one place (LDS when it fits): the owning model's
@@ -117,6 +119,7 @@ struct FlatScene {
 	std::vector<int32_t> surf_tex;       // [ns][7] texture id per slot or -1
 	std::vector<TexRec> textures;
 	std::vector<uint8_t> texels;
+	std::vector<float> texels_f;         // texels of .hdr images
 	std::vector<std::string> texture_paths;
 	// derived, device-ready
 	std::vector<ModelRec> models;
@@ -162,7 +165,11 @@ struct Error {
 };
 void read_png(const std::string& path, uint32_t& W, uint32_t& H, uint32_t& C, std::vector<uint8_t>& out);
 void read_jpeg(const std::string& path, uint32_t& W, uint32_t& H, uint32_t& C, std::vector<uint8_t>& out);    // jpeg_read.cpp
+bool is_hdr_file(const std::string& path);                                                                      // hdr_read.cpp
+void read_hdr(const std::string& path, uint32_t& W, uint32_t& H, uint32_t& C, std::vector<float>& out);
 void read_image(const std::string& path, uint32_t& W, uint32_t& H, uint32_t& C, std::vector<uint8_t>& out);   // PNG or JPEG, by content
+// image::image::load: appends the image's texels to the scene's arrays (8-bit ones to `texels`, .hdr floats to `texels_f`) and returns its record
+TexRec load_texture(FlatScene& s, const std::string& path, bool srgb);
 // work: the host's `scene_info.work` primitive filter (src/models/work_info.hpp:11-15, src/scene/load_gltf.cpp:95-99):
 // when `filter` is set, only the listed primitive indices of each named mesh are loaded (a mesh that is not listed
 // loads nothing but keeps its model); when clear, every primitive is loaded (core::renderer::load_gltf).

@@ -169,9 +169,7 @@ struct Loader {
 	const WorkFilter* work = nullptr;
 	// get_cached_texture (renderer.cpp:33-51): one texture object per file path; the sRGB flag of the FIRST request sticks
 	std::unordered_map<std::string, int32_t> tex_by_path;
-	std::vector<TexRec> textures;
-	std::vector<uint8_t> texels;
-	std::vector<std::string> texture_paths;
+	FlatScene tex_store;   // textures / texels / texels_f / texture_paths as load_texture fills them
 
 	int32_t texture(const JVal* ref, bool srgb) {
 		if (!ref) return -1;
@@ -181,16 +179,10 @@ struct Loader {
 		std::string path = g.dir + "/" + uri_decode_spaces(img.at("uri").s());
 		auto it = tex_by_path.find(path);
 		if (it != tex_by_path.end()) return it->second;
-		uint32_t W, H, C;
-		std::vector<uint8_t> px;
-		read_image(path, W, H, C, px);   // PNG or JPEG, by content (image::image::load -> stb_image)
-		if (texels.size() + px.size() > 0xFFFFFFFFull) fail(E_PARSE, "glTF: more than 4 GiB of texels");
-		TexRec t{W, H, C | (srgb ? 256u : 0u), (uint32_t)texels.size()};
-		texels.insert(texels.end(), px.begin(), px.end());
-		while (texels.size() % 16) texels.push_back(0);
-		const int32_t id = (int32_t)textures.size();
-		textures.push_back(t);
-		texture_paths.push_back(path);
+		const TexRec t = load_texture(tex_store, path, srgb);   // PNG, JPEG or Radiance HDR, by content (image::image::load -> stb_image)
+		const int32_t id = (int32_t)tex_store.textures.size();
+		tex_store.textures.push_back(t);
+		tex_store.texture_paths.push_back(path);
 		tex_by_path[path] = id;
 		return id;
 	}
@@ -396,9 +388,10 @@ void load_gltf(const std::string& path, uint32_t camera_index, uint32_t sun_ligh
 		for (int k = 0; k < 3; k++) sun13[9 + k] = col[k] * inten;  // renderer.cpp:159
 		sun13[12] = 0.004732f;                                      // sun_light::angular_radius, sun_light.hpp:10
 	}
-	out.textures = std::move(L.textures);
-	out.texels = std::move(L.texels);
-	out.texture_paths = std::move(L.texture_paths);
+	out.textures = std::move(L.tex_store.textures);
+	out.texels = std::move(L.tex_store.texels);
+	out.texels_f = std::move(L.tex_store.texels_f);
+	out.texture_paths = std::move(L.tex_store.texture_paths);
 	finalize_scene(out, cam13, have_sun ? sun13 : nullptr);
 }
 

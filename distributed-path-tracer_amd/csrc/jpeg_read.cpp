@@ -653,4 +653,23 @@ void read_image(const std::string& path, uint32_t& W, uint32_t& H, uint32_t& C, 
 	return read_png(path, W, H, C, out);   // reports anything else as "not a PNG"
 }
 
+TexRec load_texture(FlatScene& s, const std::string& path, bool srgb) {
+	uint32_t W = 0, H = 0, C = 0;
+	if (is_hdr_file(path)) {
+		std::vector<float> px;
+		read_hdr(path, W, H, C, px);
+		if (s.texels_f.size() + px.size() > 0x3FFFFFFFull) throw Error{3, "more than 4 GiB of float texels"};
+		const TexRec t{W, H, C | (srgb ? kTexSrgb : 0u) | kTexFloat, (uint32_t)s.texels_f.size()};
+		s.texels_f.insert(s.texels_f.end(), px.begin(), px.end());
+		return t;
+	}
+	std::vector<uint8_t> px;
+	read_image(path, W, H, C, px);
+	if (s.texels.size() + px.size() > 0xFFFFFFFFull) throw Error{3, "more than 4 GiB of texels"};
+	const TexRec t{W, H, C | (srgb ? kTexSrgb : 0u), (uint32_t)s.texels.size()};
+	s.texels.insert(s.texels.end(), px.begin(), px.end());
+	while (s.texels.size() % 16) s.texels.push_back(0);
+	return t;
+}
+
 }  // namespace ptx

@@ -573,12 +573,18 @@ DEV void camera_ray(const DevScene& S, const RenderParams& P, uint32_t x, uint32
 }
 
 // ------------------------------------------------------------------------------------ textures
-// image::image::read (image/image.cpp:124-141), LDR branch: byte / 255; colour channels of an sRGB image go through
-// pow(v, 2.2) — here a 256-entry table of exactly those values.
+// image::image::read (image/image.cpp:124-141). LDR: byte / 255; colour channels of an sRGB image go through pow(v, 2.2) — here a
+// 256-entry table of exactly those values. HDR (Radiance .hdr): the stored float as it is; pow(v, 2.2F) when the image was loaded as
+// sRGB (powf of ocml here, of glibc there: last-place differences, the one lookup that is not bit-exact).
 DEV float tex_chan(const DevScene& S, const TexRec& t, uint32_t px, uint32_t py, uint32_t ch) {
 	const uint32_t c = t.c_srgb & 255u;
+	const bool srgb = (t.c_srgb & kTexSrgb) != 0 && ch < 3;
+	if (t.c_srgb & kTexFloat) {
+		const float v = S.texels_f[t.offset + (py * t.w + px) * c + ch];
+		return srgb ? powf(v, 2.2F) : v;
+	}
 	const uint32_t b = S.texels[t.offset + (py * t.w + px) * c + ch];
-	return ((t.c_srgb >> 8) != 0 && ch < 3) ? S.srgb_lut[b] : (float)b / 255.0F;
+	return srgb ? S.srgb_lut[b] : (float)b / 255.0F;
 }
 // image_texture::read_pixel (image/image_texture.cpp:47-62): channels the image does not have stay 1
 DEV float4 tex_pixel(const DevScene& S, const TexRec& t, uint32_t px, uint32_t py) {

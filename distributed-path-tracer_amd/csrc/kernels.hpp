@@ -54,6 +54,7 @@ struct DevScene {
 	const SpaceRec* spaces; // distinct world->local transforms
 	const TexRec* tex;       // textures
 	const uint8_t* texels;   // 8-bit texel bytes of all textures
+	const float* texels_f;   // float texels of Radiance .hdr images (TexRec::c_srgb & kTexFloat)
 	const float* srgb_lut;   // [256] pow(b / 255, 2.2)
 	uint32_t glb_leaf_ordered; // layout of tri_isect: 1 = one record per leaf reference (leaf order), 0 = one per triangle (reached through refs)
 	uint32_t any_texture;

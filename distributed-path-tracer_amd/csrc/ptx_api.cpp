@@ -93,7 +93,7 @@ struct ptx_scene {
 	ptx_ctx* ctx = nullptr;
 	FlatScene host;
 	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr, d_isect, d_shade, d_tex, d_texels, d_lut, d_spaces, d_model_space;
-	DevBuf d_res_nodes, d_res_refs, d_res_tris;
+	DevBuf d_res_nodes, d_res_refs, d_res_tris, d_texels_f;
 	DevScene dev{};
 	bool leaf_ordered = true; // global-memory copy of the triangle records: per leaf reference (true) or per triangle (false)
 	int mode = MODE_GLOBAL;   // where the traversal arrays live: MODE_GLOBAL / MODE_LDS / MODE_HYBRID (kernels.hip)
@@ -161,6 +161,7 @@ int upload_scene(ptx_scene* sc) {
 	HIP_TRY(up(sc->d_shade, h.shade.data(), h.shade.size() * sizeof(ShadeRec), h.shade.size() * sizeof(ShadeRec)));
 	HIP_TRY(up(sc->d_tex, h.textures.data(), h.textures.size() * sizeof(TexRec), h.textures.size() * sizeof(TexRec)));
 	HIP_TRY(up(sc->d_texels, h.texels.data(), h.texels.size(), pad16(h.texels.size())));
+	HIP_TRY(up(sc->d_texels_f, h.texels_f.data(), h.texels_f.size() * 4, pad16(h.texels_f.size() * 4)));
 	{   // image::read: value = byte / 255.0F; sRGB colour channels: math::pow(value, 2.2F) (image.cpp:135-138) — same libm call, once per byte value
 		float lut[256];
 		for (int b = 0; b < 256; b++) lut[b] = std::pow(b / 255.0F, 2.2F);
@@ -188,6 +189,7 @@ int upload_scene(ptx_scene* sc) {
 	d.spaces = (const SpaceRec*)sc->d_spaces.p;
 	d.tex = (const TexRec*)sc->d_tex.p;
 	d.texels = (const uint8_t*)sc->d_texels.p;
+	d.texels_f = (const float*)sc->d_texels_f.p;
 	d.srgb_lut = (const float*)sc->d_lut.p;
 	d.glb_leaf_ordered = sc->leaf_ordered ? 1u : 0u;
 	d.any_texture = (h.any_texture || h.env_tex >= 0) ? 1u : 0u;   // the TEX kernels also carry the environment lookup
@@ -207,7 +209,7 @@ int upload_scene(ptx_scene* sc) {
 
 void release_scene_buffers(ptx_scene* sc) {
 	for (DevBuf* b : {&sc->d_models, &sc->d_surfaces, &sc->d_materials, &sc->d_nodes, &sc->d_refs, &sc->d_tris, &sc->d_vattr, &sc->d_isect, &sc->d_shade, &sc->d_tex,
-	                  &sc->d_texels, &sc->d_lut, &sc->d_spaces, &sc->d_model_space, &sc->d_res_nodes, &sc->d_res_refs, &sc->d_res_tris})
+	                  &sc->d_texels, &sc->d_texels_f, &sc->d_lut, &sc->d_spaces, &sc->d_model_space, &sc->d_res_nodes, &sc->d_res_refs, &sc->d_res_tris})
 		b->release();
 }
 
@@ -337,10 +339,10 @@ int ptx_scene_set_environment(ptx_scene* sc, const char* png_path, int srgb) {
 	if (!sc) return set_err(PTX_ERR_INVALID, "ptx_scene_set_environment: scene is NULL");
 	// the file is read before the lock is taken; the scene's host arrays are only touched under it (a render may be in flight on
 	// another thread: ptx_render holds the same mutex for its whole call)
-	uint32_t W = 0, H = 0, Cn = 0;
-	std::vector<uint8_t> px;
+	FlatScene img;   // the decoded file: one TexRec + its texels (8-bit or, for a Radiance .hdr, float)
+	TexRec rec{};
 	try {
-		if (png_path) read_image(png_path, W, H, Cn, px);   // PNG or JPEG
+		if (png_path) rec = load_texture(img, png_path, srgb != 0);   // PNG, JPEG or .hdr, by content
 	} catch (const Error& e) {
 		return set_err(e.code, e.msg);
 	} catch (const std::exception& e) {
@@ -351,14 +353,15 @@ int ptx_scene_set_environment(ptx_scene* sc, const char* png_path, int srgb) {
 	FlatScene& h = sc->host;
 	if (h.env_tex >= 0) {   // the previous map is always the last texture (appended below): drop it instead of letting them pile up
 		const TexRec old = h.textures[(size_t)h.env_tex];
-		h.texels.resize(old.offset);
+		if (old.c_srgb & kTexFloat) h.texels_f.resize(old.offset); else h.texels.resize(old.offset);
 		h.textures.pop_back();
 		h.texture_paths.pop_back();
 		h.env_tex = -1;
 	}
 	if (png_path) {
-		h.textures.push_back(TexRec{W, H, Cn | (srgb ? 256u : 0u), (uint32_t)h.texels.size()});
-		h.texels.insert(h.texels.end(), px.begin(), px.end());
+		if (rec.c_srgb & kTexFloat) { rec.offset = (uint32_t)h.texels_f.size(); h.texels_f.insert(h.texels_f.end(), img.texels_f.begin(), img.texels_f.end()); }
+		else { rec.offset = (uint32_t)h.texels.size(); h.texels.insert(h.texels.end(), img.texels.begin(), img.texels.end()); }
+		h.textures.push_back(rec);
 		h.texture_paths.push_back(png_path);
 		h.env_tex = (int32_t)h.textures.size() - 1;
 	}
@@ -476,6 +479,7 @@ int64_t ptx_scene_get_array(const ptx_scene* sc, ptx_array which, void* dst, siz
 	case PTX_ARR_TEXTURES: src = h.textures.data(); bytes = h.textures.size() * sizeof(TexRec); break;
 	case PTX_ARR_TEXELS: src = h.texels.data(); bytes = h.texels.size(); elem = 1; break;
 	case PTX_ARR_SURF_TEX: src = h.surf_tex.data(); bytes = h.surf_tex.size() * 4; break;
+	case PTX_ARR_TEXELS_F32: src = h.texels_f.data(); bytes = h.texels_f.size() * 4; break;
 	default: set_err(PTX_ERR_INVALID, "unknown array id"); return -1;
 	}
 	if (dst) {

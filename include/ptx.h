@@ -109,7 +109,8 @@ void ptx_scene_destroy(ptx_scene* scene);
 
 /* renderer::environment (LIB/core/renderer.hpp:28: std::shared_ptr<image::texture>, sampled on a miss through
  * core::equirectangular_proj, renderer.cpp:443-449 / shading_worker.cpp:28-35) = image_texture::load(png_path, srgb).
- * The miss colour becomes texture(dir) * environment_factor. png_path == NULL removes the map. PNG only. */
+ * The miss colour becomes texture(dir) * environment_factor. png_path == NULL removes the map. The file may be a PNG, a JPEG or a
+ * Radiance .hdr (by content, as stb_image decides); an .hdr keeps its float texels (image::hdr). */
 int ptx_scene_set_environment(ptx_scene* scene, const char* png_path, int srgb);
 
 typedef struct ptx_scene_info {
@@ -141,9 +142,10 @@ typedef enum ptx_array {
 	PTX_ARR_CAMERA = 10,      /* float[14]: origin basis fov tan_half_fov */
 	PTX_ARR_SUN = 11,         /* float[13] or empty */
 	PTX_ARR_MODEL_NAMES = 12, /* char[]: '\n'-separated entity names in visit order */
-	PTX_ARR_TEXTURES = 13,    /* uint32[n_textures][4]: width, height, channels | srgb << 8, byte offset into TEXELS */
+	PTX_ARR_TEXTURES = 13,    /* uint32[n_textures][4]: width, height, channels | srgb << 8 | float << 16, byte offset into TEXELS (float offset into TEXELS_F32) */
 	PTX_ARR_TEXELS = 14,      /* uint8[]: 8-bit texels of all textures (rows top to bottom, as decoded) */
-	PTX_ARR_SURF_TEX = 15     /* int32[n_surfaces][7]: texture id per material slot (normal, albedo, opacity, occlusion, roughness, metallic, emissive), -1 = none */
+	PTX_ARR_SURF_TEX = 15,    /* int32[n_surfaces][7]: texture id per material slot (normal, albedo, opacity, occlusion, roughness, metallic, emissive), -1 = none */
+	PTX_ARR_TEXELS_F32 = 16   /* float[]: texels of Radiance .hdr images (TEXTURES entries with bit 16 of the third word; their offset counts floats here) */
 } ptx_array;
 int64_t ptx_scene_get_array(const ptx_scene* scene, ptx_array which, void* dst, size_t dst_bytes);
 

@@ -126,11 +126,76 @@ def make_jpeg_fixtures(env):
     print(f"jpeg_vectors.npz written ({os.path.getsize(os.path.join(GOLD, 'jpeg_vectors.npz')) / 1024:.0f} KiB), {len(names)} Sponza digests")
 
 
+def write_hdr(path, img, rle):
+    """Radiance RGBE writer for the fixtures (img float32 [H, W, 3]): new-style run-length scanlines when `rle` (needs 8 <= W < 32768),
+    flat quadruples otherwise. What the bytes decode to is taken from the reference, not from this encoder."""
+    h, w = img.shape[:2]
+    v = img.max(-1)
+    m, e = np.frexp(v)
+    scale = np.where(v > 1e-32, m * 256.0 / np.maximum(v, 1e-38), 0.0)
+    rgbe = np.zeros((h, w, 4), np.uint8)
+    rgbe[..., :3] = np.clip(img * scale[..., None], 0, 255).astype(np.uint8)
+    rgbe[..., 3] = np.where(v > 1e-32, e + 128, 0).astype(np.uint8)
+    out = bytearray(b"#?RADIANCE\n# synthetic fixture\nFORMAT=32-bit_rle_rgbe\n\n" + f"-Y {h} +X {w}\n".encode())
+    if not rle:
+        out += rgbe.tobytes()
+    else:
+        for j in range(h):
+            out += bytes([2, 2, w >> 8, w & 255])
+            for k in range(4):
+                row = rgbe[j, :, k]
+                i = 0
+                while i < w:
+                    run = 1
+                    while i + run < w and run < 127 and row[i + run] == row[i]:
+                        run += 1
+                    if run >= 4:
+                        out += bytes([128 + run, int(row[i])]); i += run
+                    else:
+                        n = 1
+                        while i + n < w and n < 128 and not (i + n + 3 < w and row[i + n] == row[i + n + 1] == row[i + n + 2] == row[i + n + 3]):
+                            n += 1
+                        out += bytes([n]) + row[i:i + n].tobytes(); i += n
+    with open(path, "wb") as fh:
+        fh.write(bytes(out))
+
+
+def make_hdr_fixtures(env):
+    """Radiance .hdr images (image::image::load's HDR branch, stbi_loadf): decoded floats, bilinear lookups (linear and sRGB) and
+    environment-map lookups + trace() on misses of the compiled reference, on synthetic files written here."""
+    hd = os.path.join(GOLD, "hdr")
+    os.makedirs(hd, exist_ok=True)
+    rng = np.random.default_rng(8)
+    y, x = np.mgrid[0:32, 0:64]
+    sky = np.stack([0.4 + 0.3 * np.sin(x / 9.0), 0.5 + 0.4 * y / 31.0, 0.9 - 0.5 * y / 31.0], -1).astype(np.float32)
+    sky[4:8, 40:46] = (900.0, 700.0, 350.0)             # a small very bright "sun": the point of an HDR map
+    sky[20:, :] = np.round(sky[20:, :] * 4) / 4           # flat areas: long runs
+    sky += (rng.random(sky.shape) * 0.02).astype(np.float32) * (y[..., None] < 20)
+    write_hdr(os.path.join(hd, "sky_rle.hdr"), sky, True)
+    write_hdr(os.path.join(hd, "sky_flat.hdr"), sky, False)                    # W >= 8 but not run-length encoded: the first-pixel fallback
+    write_hdr(os.path.join(hd, "tiny.hdr"), (rng.random((5, 6, 3)) * np.float32(3)).astype(np.float32), False)   # W < 8: always flat
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for f in sorted(glob.glob(os.path.join(hd, "*.hdr"))):
+            tag = os.path.basename(f)[:-4]
+            subprocess.check_call([HARNESS, "image", f, tmp, "31", "256"], env=env)
+            for k in ("pixels", "uv", "sample_linear", "sample_srgb"):
+                out[f"{tag}_{k}"] = np.load(os.path.join(tmp, k + ".npy"))
+        for srgb in (0, 1):
+            d = os.path.join(tmp, f"env{srgb}")
+            subprocess.check_call([HARNESS, "envmap", CORNELL, os.path.join(hd, "sky_rle.hdr"), str(srgb), d, "9", "384"], env=env)
+            for k in ("env_in", "env_uv", "env_out", "env_trace"):
+                out[f"srgb{srgb}_{k}"] = np.load(os.path.join(d, k + ".npy"))
+    np.savez_compressed(os.path.join(GOLD, "hdr_vectors.npz"), **out)
+    print(f"hdr_vectors.npz written ({os.path.getsize(os.path.join(GOLD, 'hdr_vectors.npz')) / 1024:.0f} KiB)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--no-mean", action="store_true")
     ap.add_argument("--only-trace", action="store_true", help="regenerate trace_vectors.npz only")
     ap.add_argument("--only-jpeg", action="store_true", help="regenerate tests/golden/jpeg/* and jpeg_vectors.npz only")
+    ap.add_argument("--only-hdr", action="store_true", help="regenerate tests/golden/hdr/* and hdr_vectors.npz only")
     ap.add_argument("--n", type=int, default=1024)
     args = ap.parse_args()
     subprocess.check_call(["make", "-s", "-j8", "-C", HERE, "ref"])
@@ -138,6 +203,9 @@ def main():
     env = dict(os.environ, ORACLE_SEED="20261004")
     if args.only_jpeg:
         make_jpeg_fixtures(env)
+        return
+    if args.only_hdr:
+        make_hdr_fixtures(env)
         return
     with tempfile.TemporaryDirectory() as tmp:
         # ---- renderer::trace itself: n rays traced one after the other by ONE thread on ONE seeded mt19937 stream. Pins the
@@ -199,6 +267,7 @@ def main():
         subprocess.check_call([HARNESS, "envmap", CORNELL, ENV_PNG, "1", d, "7", "512"], env=env)
         pack(d, os.path.join(GOLD, "env_vectors.npz"))
         make_jpeg_fixtures(env)
+        make_hdr_fixtures(env)
         # a small deterministic PNG from renderer::render itself (single thread + fixed seed => reproducible)
         png = os.path.join(GOLD, "cornell_ref_64x64_16spp_4b.png")
         r = subprocess.check_output([HARNESS, "render", CORNELL, "64", "64", "16", "4", "1", png], env=env)

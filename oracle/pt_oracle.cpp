@@ -338,13 +338,14 @@ struct texture {   // 8-bit image as stb_image returns it (1-4 channels), + the 
 	int w = 0, h = 0, c = 0;
 	bool srgb = false;
 	std::vector<uint8_t> data;
+	std::vector<float> fdata;   // image::hdr (a Radiance .hdr, stbi_loadf): the floats as decoded; `data` is then empty
 };
 struct f4v { float x, y, z, w; };
-// image::image::read — image.cpp:124-141 (LDR branch): byte / 255, sRGB decode pow(v, 2.2) on colour channels
+// image::image::read — image.cpp:124-141: LDR byte / 255, HDR the stored float; sRGB decode pow(v, 2.2) on colour channels
 static inline float tex_read(const texture& t, uint32_t px, uint32_t py, uint32_t ch) {
 	uint32_t index = py * (uint32_t)t.w + px;
 	index = index * (uint32_t)t.c + ch;
-	float value = t.data[index] / 255.0F;
+	float value = t.fdata.empty() ? t.data[index] / 255.0F : t.fdata[index];
 	if (t.srgb && ch < 3) value = std::pow(value, 2.2F);
 	return value;
 }
@@ -920,7 +921,17 @@ void ora_scene_set_environment(void* p, int w, int h, int c, int srgb, const uin
 	s->has_env = data != nullptr;
 	if (!data) return;
 	s->env.w = w; s->env.h = h; s->env.c = c; s->env.srgb = srgb != 0;
+	s->env.fdata.clear();
 	s->env.data.assign(data, data + (size_t)w * h * c);
+}
+// ... from a Radiance .hdr: the decoded floats (image::hdr = true)
+void ora_scene_set_environment_f32(void* p, int w, int h, int c, int srgb, const float* data) {
+	scene_t* s = (scene_t*)p;
+	s->has_env = data != nullptr;
+	if (!data) return;
+	s->env.w = w; s->env.h = h; s->env.c = c; s->env.srgb = srgb != 0;
+	s->env.data.clear();
+	s->env.fdata.assign(data, data + (size_t)w * h * c);
 }
 // dirs[n][3] (unit) -> uv[n][2], rgba[n][4] (texture sample), colour[n][3] (x environment_factor)
 void ora_env_lookup(void* p, size_t n, const float* dirs, const float* env_factor, float* uv, float* rgba, float* colour) {

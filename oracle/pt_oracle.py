@@ -286,6 +286,56 @@ def _get_mesh(g, bufs, prim):  # renderer.cpp:177-263
     return v, t
 
 
+def _decode_hdr(path):
+    """Radiance .hdr as stb_image's stbi_loadf decodes it: float32 [H, W, 3], rgb = byte * 2^(e - 136), black when e == 0.
+    Header "#?RADIANCE" / "#?RGBE", FORMAT=32-bit_rle_rgbe, "-Y h +X w"; new-style RLE scanlines or flat RGBE quadruples."""
+    b = open(path, "rb").read()
+    lines, p = [], 0
+    while True:
+        q = b.index(b"\n", p)
+        lines.append(b[p:q].decode("latin1")); p = q + 1
+        if lines[-1] == "":
+            break
+    if lines[0] not in ("#?RADIANCE", "#?RGBE") or "FORMAT=32-bit_rle_rgbe" not in lines:
+        raise RuntimeError("unsupported HDR")
+    q = b.index(b"\n", p)
+    dim = b[p:q].decode("latin1").split(); p = q + 1
+    assert dim[0] == "-Y" and dim[2] == "+X"
+    h, w = int(dim[1]), int(dim[3])
+    rgbe = np.zeros((h, w, 4), np.uint8)
+    def flat(first):
+        n = h * w - first
+        rgbe.reshape(-1, 4)[first:] = np.frombuffer(b, np.uint8, n * 4, p).reshape(-1, 4)
+    if w < 8 or w >= 32768:
+        flat(0)
+    else:
+        for j in range(h):
+            c1, c2, l1 = b[p], b[p + 1], b[p + 2]
+            if c1 != 2 or c2 != 2 or (l1 & 0x80):
+                assert j == 0
+                flat(0)
+                break
+            assert ((l1 << 8) | b[p + 3]) == w
+            p += 4
+            for k in range(4):
+                i = 0
+                while i < w:
+                    cnt = b[p]; p += 1
+                    if cnt > 128:
+                        rgbe[j, i:i + cnt - 128, k] = b[p]; p += 1; i += cnt - 128
+                    else:
+                        rgbe[j, i:i + cnt, k] = np.frombuffer(b, np.uint8, cnt, p); p += cnt; i += cnt
+    e = rgbe[..., 3].astype(np.int32)
+    f1 = np.where(e != 0, np.ldexp(np.float32(1.0), e - 136), np.float32(0)).astype(np.float32)
+    return (rgbe[..., :3].astype(np.float32) * f1[..., None]).astype(np.float32)
+
+
+def _is_hdr(path):
+    with open(path, "rb") as fh:
+        s = fh.read(11)
+    return s.startswith(b"#?RADIANCE\n") or s.startswith(b"#?RGBE\n")
+
+
 def _decode_image(path):
     """8-bit pixels with the channel count stb_image reports (req_comp = 0): L=1, LA=2, RGB=3, RGBA=4, palette -> RGB(A)."""
     from PIL import Image
@@ -349,6 +399,11 @@ class OracleScene:
         """renderer::environment = image_texture::load(path, srgb) (renderer.hpp:28); None removes it."""
         if png_path is None:
             lib().ora_scene_set_environment(self.h, 0, 0, 0, 0, None)
+            return
+        if _is_hdr(png_path):                                 # image::hdr: float texels
+            self._env = np.ascontiguousarray(_decode_hdr(png_path), np.float32)
+            h, w, c = self._env.shape
+            lib().ora_scene_set_environment_f32(self.h, w, h, c, int(bool(srgb)), _p(self._env))
             return
         self._env = np.ascontiguousarray(_decode_image(png_path), np.uint8)
         h, w, c = self._env.shape

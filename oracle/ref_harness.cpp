@@ -510,11 +510,19 @@ static int cmd_envmap(const char* gltf, const char* png, int srgb, const std::st
 static int cmd_image(const char* file, const std::string& dir, uint64_t seed, size_t n) {
 	std::filesystem::create_directories(dir);
 	int w = 0, h = 0, c = 0;
-	unsigned char* px = stbi_load(file, &w, &h, &c, 0);
-	if (!px) { fprintf(stderr, "image: stbi_load failed: %s\n", stbi_failure_reason()); return 2; }
-	std::vector<uint8_t> data(px, px + (size_t)w * h * c);
-	stbi_image_free(px);
-	save(dir, "pixels", data, {(size_t)h, (size_t)w, (size_t)c});
+	if (stbi_is_hdr(file)) {   // image::load's HDR branch: stbi_loadf, the floats are kept
+		float* pf = stbi_loadf(file, &w, &h, &c, 0);
+		if (!pf) { fprintf(stderr, "image: stbi_loadf failed: %s\n", stbi_failure_reason()); return 2; }
+		std::vector<float> data(pf, pf + (size_t)w * h * c);
+		stbi_image_free(pf);
+		save(dir, "pixels", data, {(size_t)h, (size_t)w, (size_t)c});
+	} else {
+		unsigned char* px = stbi_load(file, &w, &h, &c, 0);
+		if (!px) { fprintf(stderr, "image: stbi_load failed: %s\n", stbi_failure_reason()); return 2; }
+		std::vector<uint8_t> data(px, px + (size_t)w * h * c);
+		stbi_image_free(px);
+		save(dir, "pixels", data, {(size_t)h, (size_t)w, (size_t)c});
+	}
 	pcg32 g(seed);
 	std::vector<float> uv, lin, srgb;
 	auto tl = image::image_texture::load(file, false), ts = image::image_texture::load(file, true);

@@ -645,3 +645,27 @@ def test_config4_5_full_frame_properties(atrium5):
     for r in range(8):
         s.render(W, H, spp, b, accum=acc, shard=(r, 8, 64))
     np.testing.assert_array_equal(_bits(acc), _bits(full))
+
+
+def test_hdr_environment_map_matches_oracle(ptx, ctx, ora):
+    """A Radiance .hdr as renderer::environment (float texels, values up to 900): per-sample radiance of an open scene against the
+    oracle (whose lookups are pinned bit-exact to the reference: test_hdr_environment_lookup_bit_exact_in_the_oracle), loaded as
+    linear (bit-level agreement of the lookup; radiance to libm ulps) and as sRGB (powf per tap on the device: ocml vs glibc)."""
+    import os
+    from conftest import ROOT, oracle_from_dict, product_from_dict
+    hdr = os.path.join(ROOT, "tests", "golden", "hdr", "sky_rle.hdr")
+    d = _proc().plaza_scene(level=2, sun=False, alpha=True)
+    o, s = oracle_from_dict(ora, d), product_from_dict(ptx, ctx, d)
+    W, H, spp, b = 80, 45, 4, 5
+    for srgb in (False, True):
+        o.set_environment(hdr, srgb)
+        s.set_environment(hdr, srgb)
+        ref = o.render_samples(ora.make_cfg(W, H, spp, b), threads=0)
+        got = np.zeros_like(ref)
+        for k in range(spp):
+            a, _ = s.render(W, H, 1, b, sample0=k)
+            got[:, :, k] = a[..., :3]
+        assert np.isfinite(got).all() and ref.max() > 50                      # paths that escape into the bright part of the map
+        err = np.abs(got - ref).max(-1) / np.maximum(np.abs(ref).max(-1), 1e-3)
+        assert (err < 1e-3).mean() > 0.99, f"srgb={srgb}: {(err < 1e-3).mean():.4%}"
+    s.set_environment(None)

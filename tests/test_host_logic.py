@@ -609,3 +609,66 @@ def test_jpeg_refusals_and_malformed_files(ptx, tmp_path):
             assert px.ndim == 3
         except ptx.PtxError as e:
             assert e.code in (ptx.ERR_PARSE, ptx.ERR_UNSUPPORTED, ptx.ERR_IO), e
+
+
+# ---------------------------------------------------------------------------- Radiance .hdr images (image::image::load, HDR branch)
+@pytest.mark.parametrize("tag", ["sky_rle", "sky_flat", "tiny"])
+def test_hdr_decode_matches_reference(ptx, ora, tmp_path, tag):
+    """csrc/hdr_read.cpp (and the oracle's numpy reader) against the floats stb_image's stbi_loadf produced in the compiled reference —
+    run-length scanlines, a file that is not run-length encoded, a file too narrow for RLE: bit-exact floats (byte * 2^(e - 136))."""
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "hdr_vectors.npz")))
+    path = os.path.join(ROOT, "tests", "golden", "hdr", tag + ".hdr")
+    ref = g[tag + "_pixels"]
+    np.testing.assert_array_equal(ora._decode_hdr(path).view(np.uint32), ref.view(np.uint32))
+    s = ptx.Scene.load_gltf(None, CORNELL)
+    s.set_environment(path, False)                            # host-only scene: decodes, keeps the floats
+    tex = s.array(ptx.ARR_TEXTURES)[-1]
+    w, h, cs, off = (int(v) for v in tex)
+    assert (h, w, cs & 255) == ref.shape and cs & (1 << 16)
+    fl = s.array(ptx.ARR_TEXELS_F32)[off:off + ref.size].reshape(ref.shape)
+    np.testing.assert_array_equal(fl.view(np.uint32), ref.view(np.uint32))
+    n_tex = s.info()["n_textures"]
+    s.set_environment(os.path.join(ROOT, "tests", "golden", "jpeg", "s444.jpg"), True)   # replaced by an 8-bit image: the floats go away
+    assert s.info()["n_textures"] == n_tex and len(s.array(ptx.ARR_TEXELS_F32)) == 0
+
+
+def test_hdr_environment_lookup_bit_exact_in_the_oracle(cornell_oracle, ora):
+    """renderer::trace's miss branch with a Radiance .hdr as renderer::environment: equirectangular_proj + image_texture::sample on float
+    texels (+ pow(v, 2.2F) when loaded as sRGB) + environment_factor, against the compiled reference (384 directions incl. the six axes)."""
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "hdr_vectors.npz")))
+    path = os.path.join(ROOT, "tests", "golden", "hdr", "sky_rle.hdr")
+    try:
+        for srgb in (0, 1):
+            cornell_oracle.set_environment(path, srgb=bool(srgb))
+            uv, rgba, _ = cornell_oracle.env_lookup(g[f"srgb{srgb}_env_in"], (0.5, 1.25, 2.0))
+            np.testing.assert_array_equal(uv.view(np.uint32), g[f"srgb{srgb}_env_uv"].view(np.uint32))
+            np.testing.assert_array_equal(rgba.view(np.uint32), g[f"srgb{srgb}_env_out"].view(np.uint32))
+            d = g[f"srgb{srgb}_env_in"].astype(np.float32)
+            ln = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], dtype=np.float32)
+            _, _, col = cornell_oracle.env_lookup(d * (np.float32(1) / ln)[:, None], (0.5, 1.25, 2.0))      # trace() sees ray::get_dir()
+            np.testing.assert_array_equal(col.view(np.uint32), g[f"srgb{srgb}_env_trace"][:, :3].view(np.uint32))
+        assert g["srgb0_env_out"].max() > 100                     # the map really is high dynamic range
+    finally:
+        cornell_oracle.set_environment(None)
+
+
+def test_malformed_hdr_is_an_error_or_an_image(ptx, tmp_path):
+    """Truncated / corrupted Radiance files: an error code or an image, never a crash or an out-of-bounds read."""
+    import random
+    src = open(os.path.join(ROOT, "tests", "golden", "hdr", "sky_rle.hdr"), "rb").read()
+    s = ptx.Scene.load_gltf(None, CORNELL)
+    rnd = random.Random(4)
+    cases = [src[:rnd.randrange(1, len(src))] for _ in range(40)]
+    for _ in range(40):
+        b = bytearray(src)
+        for _ in range(rnd.randrange(1, 5)):
+            b[rnd.randrange(11, len(b))] = rnd.randrange(256)
+        cases.append(bytes(b))
+    cases += [b"#?RADIANCE\n\n-Y 4 +X 4\n", b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n+Y 4 +X 4\n" + b"\0" * 64,
+              b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 99999999 +X 99999999\n", b"#?RGBE\nFORMAT=32-bit_rle_rgbe\n\n-Y -3 +X 4\n"]
+    for c in cases:
+        (tmp_path / "m.hdr").write_bytes(c)
+        try:
+            s.set_environment(str(tmp_path / "m.hdr"), False)
+        except ptx.PtxError as e:
+            assert e.code in (ptx.ERR_PARSE, ptx.ERR_UNSUPPORTED, ptx.ERR_IO), e
