@@ -149,12 +149,20 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal on a box with fewer GPUs than ranks (not a measurement): BENCH_REHEARSAL=1 puts every rank on GPU 0 and reduces over
+    # gloo instead of RCCL (RCCL refuses two ranks on one device) — the whole multi-process flow except the collective's transport.
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: no GPU for local rank {local_rank} (this benchmark has no CPU path)")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # BENCH_FORCE_DIST: exercise the RCCL path with one rank
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ptx = importlib.import_module("distributed-path-tracer_amd")
     mg = importlib.import_module("distributed-path-tracer_amd.multigpu")
@@ -246,7 +254,8 @@ def main():
             "metric": f"Msamples/sec, Cornell box {W}x{H}, {what}, {BOUNCES} bounces (camera paths traced per second)",
             "value": round(samples / dt / 1e6, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak" if mode == "weak" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if mode == "weak" else "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" + (" — REHEARSAL: all ranks share GPU 0, gloo reduce; not a measurement" if rehearsal else ""),
             "config": {"workload": f"Cornell box (scenes/cornell-box/cornell.gltf) {W}x{H}, {spp_total} spp per frame, {BOUNCES} bounces "
                                    f"(BASELINE.json configs[1]) on {world} x MI355X",
                        "spp_total": spp_total,
