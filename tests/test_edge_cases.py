@@ -211,3 +211,55 @@ def test_concurrent_callers(scene, ptx):
     for k in range(8):
         x0, y0, w, h = tiles[k % 4]
         np.testing.assert_array_equal(out[k], full[y0:y0 + h, x0:x0 + w])
+
+
+def _glass_stack(n_layers, opacity):
+    """n_layers quads one behind the other in front of the camera, all with the same opacity (< 1: every hit may pass through,
+    renderer.cpp:466-472), nothing else: flat arrays for Scene.from_arrays / the oracle."""
+    proc = _proc()
+    d = proc.plaza_scene(level=0, sun=False, alpha=False)
+    verts, tris = [], []
+    for k in range(n_layers):
+        z = -2.0 - 0.01 * k
+        q = np.zeros((4, 11), np.float32)
+        q[:, :3] = [[-50, -50, z], [50, -50, z], [50, 50, z], [-50, 50, z]]
+        q[:, 7] = 1.0                      # normal +z (towards the camera)
+        q[:, 8] = 1.0                      # tangent +x
+        verts.append(q)
+        tris.append(np.array([[0, 1, 2], [0, 2, 3]], np.uint32) + 4 * k)
+    cam = np.zeros(13, np.float32)
+    cam[3] = cam[7] = cam[11] = 1.0        # identity basis at the origin, looking down -z
+    cam[12] = 0.6
+    return dict(model_xform=np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1]], np.float32), model_surf=np.array([[0, 1]], np.int32),
+                surf_range=np.array([[0, 4 * n_layers, 0, 2 * n_layers]], np.int32), vertices=np.concatenate(verts), triangles=np.concatenate(tris),
+                materials=np.array([[0.8, 0.8, 0.8, opacity, 0.5, 0.0, 0, 0, 0, 1.33, 0]], np.float32), camera=cam, sun=None)
+
+
+def test_many_pass_throughs_without_consuming_bounces(ptx, ctx, ora):
+    """Opacity pass-through (renderer.cpp:466-472) re-traces from behind the surface WITHOUT consuming a bounce: 40 half-transparent
+    layers, 2 bounces — paths cross up to 40 layers at depth 0 (pass counter 0..40 in the RNG key). Per-sample parity with the oracle."""
+    from conftest import oracle_from_dict
+    d = _glass_stack(40, 0.5)
+    s, o = _from(ptx, ctx, d), oracle_from_dict(ora, d)
+    W, H, spp, b = 24, 16, 6, 2
+    ref = o.render_samples(ora.make_cfg(W, H, spp, b), threads=0)
+    got = np.zeros_like(ref)
+    rays = 0
+    for k in range(spp):
+        a, st = s.render(W, H, 1, b, sample0=k)
+        got[:, :, k] = a[..., :3]
+        rays += st["rays"]
+    assert rays > 2.5 * W * H * spp                         # pass-throughs are extra renderer::intersect calls
+    err = np.abs(got - ref).max(-1) / np.maximum(np.abs(ref).max(-1), 1e-3)
+    assert (err < 1e-3).mean() > 0.995
+
+
+def test_pass_through_cap_is_a_documented_safety_bound(ptx, ctx):
+    """A path that would pass through more than 4096 surfaces at one depth ends there (kernels.hip shade_vertex; the reference would
+    recurse until its stack overflows, renderer.cpp:466-472 has no bound): 4200 fully transparent layers (opacity 0) — the render
+    terminates, every sample is finite, black (nothing was ever added) and costs exactly 4097 closest-hit queries."""
+    d = _glass_stack(4200, 0.0)
+    s = _from(ptx, ctx, d)
+    a, st = s.render(4, 3, 2, 3)
+    assert np.isfinite(a).all() and (a[..., :3] == 0).all() and (a[..., 3] == 2).all()
+    assert st["rays"] == 4 * 3 * 2 * 4097
