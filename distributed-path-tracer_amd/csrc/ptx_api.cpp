@@ -71,7 +71,7 @@ void srgb_thresholds(float thr[256]) {
 }
 
 constexpr size_t kLdsBudget = 160 * 1024;
-constexpr size_t kLeafOrderMaxBytes = (size_t)1 << 40;   // set by measurement (DESIGN.md "Residency modes")  // per-CU LDS on gfx950; one workgroup may take all of it
+constexpr size_t kLeafOrderMaxBytes = (size_t)1 << 40;   // never reached: see decide_mode  // per-CU LDS on gfx950; one workgroup may take all of it
 
 }  // namespace
 
@@ -113,9 +113,10 @@ void decide_mode(ptx_scene* sc) {
 	else sc->mode = getenv("PTX_NO_HYBRID") ? MODE_GLOBAL : MODE_HYBRID;
 	if (sc->mode == MODE_GLOBAL) for (auto& sr : h.surfaces) sr.lds_root = 0xFFFFFFFFu;
 	sc->lds_bytes = sc->mode == MODE_GLOBAL ? 0 : h.res_bytes;
-	// Leaf-ordered records duplicate a triangle once per leaf that references it (12x on deep SAH trees). While the duplicated array
-	// stays cache-resident that costs nothing and saves a dependent fetch per test; once it outgrows the caches (the Infinity Cache
-	// also holds the ray streams) the smaller per-triangle layout wins. PTX_LEAF_ORDER=0/1 overrides (measurement).
+	// Leaf-ordered records duplicate a triangle once per leaf that references it (12x on deep SAH trees) and save a dependent fetch per
+	// test. Measured up to 144 MB of records (the 262 k-triangle atrium, against 25 MB per triangle + references): the leaf order still
+	// wins by 8 % — the dependent fetch costs more than the cache footprint (profiles/round2_ab_layout_blocksize.txt), so the threshold
+	// is out of reach of any scene that fits the other limits. PTX_LEAF_ORDER=0/1 overrides (measurement).
 	sc->leaf_ordered = h.kd_refs.size() * 48 <= kLeafOrderMaxBytes;
 	if (const char* e = getenv("PTX_LEAF_ORDER")) sc->leaf_ordered = e[0] != '0';
 }
