@@ -3,6 +3,7 @@
 // :124-141). This reader produces the same floats: header "#?RADIANCE" / "#?RGBE", FORMAT=32-bit_rle_rgbe, "-Y h +X w" orientation
 // only (what stb accepts), new-style run-length scanlines or flat RGBE quadruples, and per pixel
 //     rgb = byte * ldexp(1.0f, e - (128 + 8))   (exact in binary32),   black when e == 0;   three channels.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -57,6 +58,11 @@ void read_hdr(const std::string& path, uint32_t& W, uint32_t& H, uint32_t& C, st
 	const long w = strtol(endp + 3, nullptr, 10);
 	if (w <= 0 || h <= 0 || w > (1 << 24) || h > (1 << 24) || (uint64_t)w * (uint64_t)h > (1ull << 28)) bad(path, "bad image size");
 	W = (uint32_t)w; H = (uint32_t)h; C = 3;
+	{   // the header alone must not be able to demand gigabytes: even the best run-length coding spends 4 + 4 * 2 * ceil(W / 127) bytes
+		// per scanline (flat data: 4 per pixel)
+		const uint64_t per_line = (W < 8 || W >= 32768) ? (uint64_t)W * 4 : 4 + 8 * (((uint64_t)W + 126) / 127);
+		if ((uint64_t)(file.size() - p) < std::min<uint64_t>(per_line, (uint64_t)W * 4) * H) bad(path, "truncated file");
+	}
 	out.assign((size_t)W * H * 3, 0.f);
 	auto get8 = [&]() -> int { return p < file.size() ? file[p++] : 0; };
 	auto convert = [&](float* o, const uint8_t* in) {

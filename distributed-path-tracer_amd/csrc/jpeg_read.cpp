@@ -354,6 +354,11 @@ struct Decoder {
 		mcu_w = h_max * 8; mcu_h = v_max * 8;
 		mcu_x = ((int)W + mcu_w - 1) / mcu_w; mcu_y = ((int)H + mcu_h - 1) / mcu_h;
 		if ((uint64_t)W * H > (1ull << 28)) bad(path, "image too large");
+		{   // a header must not be able to demand gigabytes from a tiny file: every 8 x 8 block costs at least one bit of entropy-coded data
+			uint64_t blocks = 0;
+			for (int i = 0; i < n_comp; i++) blocks += (uint64_t)mcu_x * mcu_y * comp[i].h * comp[i].v;
+			if ((uint64_t)(end - p) * 8 < blocks) bad(path, "truncated file");
+		}
 		for (int i = 0; i < n_comp; i++) {
 			Component& c = comp[i];
 			c.x = ((int)W * c.h + h_max - 1) / h_max;
