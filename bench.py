@@ -11,9 +11,9 @@ N = 1: one process, one GPU. N > 1: one process per GPU over RCCL (torch.distrib
 plain shell (no WORLD_SIZE) with --gpus N > 1 it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
 CHILD process (before anything here touches a GPU), relays rank 0's JSON line and exits with the child's code. Under
 torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE set, as the driver launches it) it is one rank of the job.
-Default for N > 1 is STRONG scaling: the same 256-spp frame, each rank tracing its contiguous share of the sample indices of every
-pixel (--shard tiles: interleaved 64x64 image tiles instead), then ONE RCCL sum-reduce of the float32 accumulation buffer onto
-rank 0 inside the timed region. --weak: every rank traces 256 spp of its own (the frame gets N*256).
+Default for N > 1 is STRONG scaling: the same 256-spp frame, its 64x64 image tiles dealt round-robin to the ranks (--shard samples:
+each rank traces a contiguous share of the sample indices of every pixel instead), then ONE RCCL sum-reduce of the float32
+accumulation buffer onto rank 0 inside the timed region. --weak: every rank traces 256 spp of its own (the frame gets N*256).
 
 Prints ONE JSON line on rank 0 (bench contract): value = whole-job Msamples/s; plus
   roofline     — dominant kernel (k_render_pass), bound by the resource that limits it (VALU issue), with the HBM view beside it
@@ -132,8 +132,9 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel of the frame (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
-    ap.add_argument("--shard", choices=("samples", "tiles"), default="samples",
-                    help="how ONE frame is split over N ranks: contiguous shares of the sample indices (default) or interleaved 64x64 tiles")
+    ap.add_argument("--shard", choices=("tiles", "samples"), default="tiles",
+                    help="how ONE frame is split over N ranks: interleaved 64x64 image tiles (default; BASELINE.json: \"image tiles shard naturally "
+                         "across the 8 GPUs\") or contiguous shares of the sample indices of every pixel")
     ap.add_argument("--spp-per-pass", type=int, default=0, help="samples of every pixel per kernel launch (0 = the library's default)")
     ap.add_argument("--weak", action="store_true", help="weak scaling instead: every rank traces --spp samples of its own")
     args = ap.parse_args()
