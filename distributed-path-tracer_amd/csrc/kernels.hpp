@@ -104,6 +104,26 @@ struct IntersectArgs {
 	uint2* spill;                                // [grid * waves per block][kSpillWords]
 };
 
+// Workspace of the queue-based pipeline (wavefront.hip). A PAIR is (ray, surface whose box it enters); the pairs of a ray are
+// consecutive, in surface order. Sized for the worst case (every ray enters every surface): what is touched is what is used.
+struct WfBuffers {
+	float4* pair_ray;              // [pairs][2]: (local origin, surface id bits) (local direction, -)
+	float4* pair_hit;              // [pairs]: (local t, global triangle id bits, beta, gamma); t = -1: the walk found nothing
+	uint32_t* queue;               // [n_surfaces][queue_cap] pair indices, one queue per surface
+	uint32_t queue_cap;            // rays of the launch
+	uint32_t* first;               // [rays] first pair of the ray
+	unsigned long long* mask;      // [rays] bit u: the ray enters surface u
+	uint32_t* ctr;                 // counters block, zeroed per launch (wavefront.hip: kWfCtr*)
+	uint32_t* sched;               // [n_surfaces][1 + kWfStripes][kWfSchedStride]: per queue a `done` word and one hand-out counter per stripe, 256 bytes apart; zeroed per launch
+	uint2* spill;                  // [wf_traverse_grid * 4 waves][kSpillWords]
+};
+constexpr size_t kWfCtrBytes = 192 * 4;   // [0] pairs, [64 + u] queue lengths, [128 + u] hand-out positions, [160 ..] PTX_WF_PROF region counters
+constexpr uint32_t kWfStripes = 16, kWfSchedStride = 64;
+inline size_t wf_sched_bytes(size_t n_surf) { return n_surf * (kWfStripes + 1u) * kWfSchedStride * 4; }
+constexpr int kWfMaxSurfaces = 64;   // surface masks are one 64-bit word
+inline int wf_traverse_grid(int n_cu) { return n_cu * 8; }   // 256-thread workgroups, 8 per CU = 8 waves per SIMD
+hipError_t launch_wf_intersect(const DevScene& S, const IntersectArgs& A, size_t first_ray, uint32_t n, const WfBuffers& W, int n_cu, hipStream_t stream);
+
 hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, int mode, size_t lds_bytes, int grid,
                               hipStream_t stream);
 hipError_t launch_resolve(const float4* sample_rad, float4* accum, const uint32_t* pixels, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream);

@@ -82,6 +82,7 @@ struct ptx_ctx {
 	int n_cu = 0;
 	std::mutex mu;
 	DevBuf queues, sample_rad, counters, spill, stage_a, stage_b, pixel_list, srgb_thr;
+	DevBuf wf_pair_ray, wf_pair_hit, wf_queue, wf_first, wf_mask, wf_ctr, wf_sched, wf_spill;   // workspace of the queue-based pipeline (wavefront.hip)
 	std::vector<hipEvent_t> events;
 	// pixel list of the last sharded render (ptx_render_cfg::shard_*), kept on the device: a frame is usually rendered again
 	// with the same sharding (sample ranges, benchmark steps)
@@ -263,6 +264,7 @@ static void ctx_release(ptx_ctx* c) {
 	(void)hipStreamSynchronize(c->stream);
 	for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
 	c->queues.release(); c->spill.release(); c->sample_rad.release(); c->counters.release(); c->stage_a.release(); c->stage_b.release(); c->pixel_list.release(); c->srgb_thr.release();
+	c->wf_pair_ray.release(); c->wf_pair_hit.release(); c->wf_queue.release(); c->wf_first.release(); c->wf_mask.release(); c->wf_ctr.release(); c->wf_sched.release(); c->wf_spill.release();
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -490,6 +492,39 @@ int64_t ptx_scene_get_array(const ptx_scene* sc, ptx_array which, void* dst, siz
 	return (int64_t)(bytes / elem);
 }
 
+namespace {
+
+// Scenes the queue-based pipeline (wavefront.hip) takes: trees in global memory, a model of many surfaces (where the fused kernel's
+// waves run nearly empty), at most 64 surfaces (one mask word per ray). PTX_WAVEFRONT=0/1 overrides the choice (measurement).
+constexpr size_t kWfMaxPairs = 96u << 20;   // pairs the workspace is sized for: 48 B each + 4 B of queue
+bool use_wavefront(const ptx_scene* sc) {
+	const size_t n_surf = sc->host.surfaces.size();
+	if (n_surf == 0 || n_surf > (size_t)kWfMaxSurfaces) return false;
+	int32_t max_per_model = 0;
+	for (const ModelRec& mr : sc->host.models) max_per_model = std::max(max_per_model, mr.n_surfaces);
+	bool on = max_per_model >= 8 && sc->mode != MODE_LDS;
+	if (const char* e = getenv("PTX_WAVEFRONT")) on = e[0] == '1';
+	return on;
+}
+hipError_t wf_workspace(ptx_ctx* c, size_t rays, size_t n_surf, WfBuffers& W) {
+	const size_t pairs = rays * n_surf;
+	hipError_t e;
+	if ((e = c->wf_pair_ray.ensure(pairs * 32)) != hipSuccess) return e;
+	if ((e = c->wf_pair_hit.ensure(pairs * 16)) != hipSuccess) return e;
+	if ((e = c->wf_queue.ensure(pairs * 4)) != hipSuccess) return e;
+	if ((e = c->wf_first.ensure(rays * 4)) != hipSuccess) return e;
+	if ((e = c->wf_mask.ensure(rays * 8)) != hipSuccess) return e;
+	if ((e = c->wf_ctr.ensure(kWfCtrBytes)) != hipSuccess) return e;
+	if ((e = c->wf_sched.ensure(wf_sched_bytes(n_surf))) != hipSuccess) return e;
+	if ((e = c->wf_spill.ensure((size_t)wf_traverse_grid(c->n_cu) * 4 * (size_t)kSpillWords * sizeof(uint2))) != hipSuccess) return e;
+	W.pair_ray = (float4*)c->wf_pair_ray.p; W.pair_hit = (float4*)c->wf_pair_hit.p; W.queue = (uint32_t*)c->wf_queue.p;
+	W.queue_cap = (uint32_t)rays;
+	W.first = (uint32_t*)c->wf_first.p; W.mask = (unsigned long long*)c->wf_mask.p; W.ctr = (uint32_t*)c->wf_ctr.p; W.sched = (uint32_t*)c->wf_sched.p; W.spill = (uint2*)c->wf_spill.p;
+	return hipSuccess;
+}
+
+}  // namespace
+
 int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_render_stats* stats) {
 	if (!sc || !cfg || !accum) return set_err(PTX_ERR_INVALID, "ptx_render: NULL argument");
 	if (!sc->ctx) return set_err(PTX_ERR_NO_DEVICE, "ptx_render: scene was created without a GPU context (no CPU path exists)");
@@ -663,10 +698,33 @@ int ptx_intersect_batch(ptx_scene* sc, const ptx_rays* r, size_t n, const ptx_hi
 		if (hh->nx) { A.nx = o + k * n; A.ny = o + (k + 1) * n; A.nz = o + (k + 2) * n; k += 3; }
 		if (hh->u) { A.u = o + k * n; A.v = o + (k + 1) * n; }
 	}
-	const int grid = (int)std::min<size_t>((size_t)c->n_cu, (n + kBlock - 1) / kBlock);
-	HIP_TRY(c->spill.ensure((size_t)c->n_cu * (kBlock / 64) * (size_t)kSpillWords * sizeof(uint2)));
-	A.spill = (uint2*)c->spill.p;
-	HIP_TRY(launch_intersect(sc->dev, A, sc->mode, sc->lds_bytes, grid, c->stream));
+	if (use_wavefront(sc)) {
+		// queue-based pipeline, a slice of the batch at a time (the workspace is sized for every ray entering every surface)
+		const size_t n_surf = sc->host.surfaces.size();
+		const size_t slice = std::min<size_t>(n, std::max<size_t>(65536, kWfMaxPairs / n_surf));
+		WfBuffers W{};
+		HIP_TRY(wf_workspace(c, slice, n_surf, W));
+		for (size_t first = 0; first < n; first += slice) {
+			HIP_TRY(launch_wf_intersect(sc->dev, A, first, (uint32_t)std::min(slice, n - first), W, c->n_cu, c->stream));
+#ifdef PTX_WF_PROF
+			uint32_t ctr[192];
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			HIP_TRY(hipMemcpy(ctr, W.ctr, sizeof ctr, hipMemcpyDeviceToHost));
+			static const char* names[8] = {"outer_round", "busy_round", "node_step", "tri_test", "hand_out", "unit_fetch", "pop", "stack_spill"};
+			fprintf(stderr, "WFPROF rays %zu pairs %u (%.2f per ray)\n", std::min(slice, n - first), ctr[0], (double)ctr[0] / (double)std::min(slice, n - first));
+			for (int k = 0; k < 8; k++)
+				fprintf(stderr, "WFPROF %-12s trips %10u lanes %11u  util %.3f  lanes/pair %.2f\n", names[k], ctr[160 + 2 * k], ctr[161 + 2 * k],
+				        ctr[160 + 2 * k] ? (double)ctr[161 + 2 * k] / (64.0 * ctr[160 + 2 * k]) : 0.0, (double)ctr[161 + 2 * k] / (double)ctr[0]);
+			static const char* tn[6] = {"kernel", "unit_fetch", "hand_out", "pop", "descend", "leaf"};
+			for (int k = 0; k < 6; k++) fprintf(stderr, "WFCLK %-10s %10u kcycles summed over waves (%.1f %%)\n", tn[k], ctr[176 + k], 100.0 * ctr[176 + k] / (double)ctr[176]);
+#endif
+		}
+	} else {
+		const int grid = (int)std::min<size_t>((size_t)c->n_cu, (n + kBlock - 1) / kBlock);
+		HIP_TRY(c->spill.ensure((size_t)c->n_cu * (kBlock / 64) * (size_t)kSpillWords * sizeof(uint2)));
+		A.spill = (uint2*)c->spill.p;
+		HIP_TRY(launch_intersect(sc->dev, A, sc->mode, sc->lds_bytes, grid, c->stream));
+	}
 	if (!dev) {
 		void* dst[14] = {hh->distance, hh->surface, hh->triangle, hh->b0, hh->b1, hh->b2, hh->px, hh->py, hh->pz, hh->nx, hh->ny, hh->nz, hh->u, hh->v};
 		const void* srcs[14] = {A.distance, A.surface, A.triangle, A.b0, A.b1, A.b2, A.px, A.py, A.pz, A.nx, A.ny, A.nz, A.u, A.v};

@@ -1,0 +1,493 @@
+// Queue-based ("wavefront") intersection for scenes whose trees live in global memory and whose models have many surfaces
+// (a Sponza-class mesh: one model, dozens of surfaces, hundreds of thousands of triangles).
+//
+// In the fused kernel (kernels.hip) a wave owns 64 rays from start to end; on such a scene a ray enters 3-5 of the surface
+// boxes, the 64 rays of a wave enter different ones, every tree walk has its own length and every step of it is a dependent
+// fetch from L2 / HBM: the measured result is 6 % of the lanes on in the tree loops and 56 % of the wave-cycles parked on
+// s_waitcnt (profiles/round2_pmc_atrium*.txt). Here the unit of work is the PAIR (ray, surface it enters):
+//   k_wf_classify  one ray per lane: local ray per model space, model box, surface boxes (scene::model::intersect, model.cpp:27-60;
+//                  core::mesh::intersect's box test, mesh.cpp:308-315) -> the ray's pairs, appended to one queue per surface
+//   k_wf_traverse  persistent waves that eat the queues: every lane walks ONE pair's tree (core::mesh::intersect, mesh.cpp:300-405)
+//                  and takes the next pair as soon as its walk ends, so lanes stay busy whatever the walk lengths; 256-thread
+//                  blocks and a traversal-only register footprint give 8 waves per SIMD (twice the fused kernel's) to cover the
+//                  fetch latency; queues are dealt to XCDs surface by surface so that each L2 sees a part of the geometry
+//   k_wf_merge_*   one ray per lane again: the ray's pair results in surface order = model::intersect's loop (first surface wins
+//                  ties on the local distance), then renderer::intersect's loop over models (first model wins ties on the world
+//                  distance, renderer.cpp:663-669)
+// Every arithmetic operation on a ray is the one the fused kernel performs (same device functions); only where and when it
+// happens differs, so results are bitwise those of the fused kernel and of the reference.
+#include "device_core.hpp"
+
+namespace ptx {
+
+constexpr int kWfBlock = 256;              // threads per workgroup of the traverse / merge kernels
+constexpr int kWfClassifyBlock = 1024;     // ... of the classify kernel: queue space is reserved per workgroup
+#ifndef PTX_WF_UNIT
+#define PTX_WF_UNIT 64
+#endif
+constexpr uint32_t kWfUnit = PTX_WF_UNIT;  // queue entries a wave takes per counter fetch and stages into its LDS slice
+#ifndef PTX_WF_LDS_STACK
+#define PTX_WF_LDS_STACK 8
+#endif
+#ifndef PTX_WF_GRAB
+#define PTX_WF_GRAB 256
+#endif
+constexpr uint32_t kWfGrab = PTX_WF_GRAB;  // queue entries a wave reserves per atomic (a multiple of kWfUnit)
+constexpr int kWfLdsStack = PTX_WF_LDS_STACK;   // traversal-stack levels kept in LDS between the register levels and the global-memory overflow
+#ifndef PTX_WF_REFILL_MIN
+#define PTX_WF_REFILL_MIN 8
+#endif
+constexpr uint32_t kWfRefillMin = PTX_WF_REFILL_MIN;   // idle lanes that make a hand-out of new pairs worth its instructions
+
+// counters block (uint32): [0] pairs allocated, [kWfCtrLen + u] entries in queue u
+constexpr uint32_t kWfCtrLen = 64;
+
+// PTX_WF_PROF builds: wave-level trips and active lanes per region of k_wf_traverse, added into ctr[kWfCtrProf ..] (measurement only)
+[[maybe_unused]] constexpr uint32_t kWfCtrProf = 160;
+#ifdef PTX_WF_PROF
+#define WFPROF(k) do { const uint64_t m_ = __ballot(true); pl[k] += 1u; pt[k] += (lane == (uint32_t)(__ffsll((long long)m_) - 1)) ? 1u : 0u; } while (0)
+// wave-level clock spent per region (kilocycles, lane 0 adds it up): T0 / T1 bracket a region executed under wave-uniform control flow
+#define WFT0() const uint64_t t0_ = __builtin_amdgcn_s_memtime()
+#define WFT1(k) do { tc[k] += __builtin_amdgcn_s_memtime() - t0_; } while (0)
+#else
+#define WFPROF(k) do { } while (0)
+#define WFT0() do { } while (0)
+#define WFT1(k) do { } while (0)
+#endif
+
+DEV uint32_t lane_id() { return threadIdx.x & 63u; }
+DEV uint32_t rank_in(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
+// the local ray of model space `spc` (geometry/ray.cpp:10-15), as scene_traverse computes it
+DEV void to_space(const SpaceRec& SP, V3 o, V3 d, V3& lo, V3& ld, V3& inv) {
+	lo = mulmv(SP.inv_basis, o) + mk(SP.inv_origin[0], SP.inv_origin[1], SP.inv_origin[2]);
+	ld = normalize(mulmv(SP.inv_basis, d));
+	inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+}
+
+// ------------------------------------------------------------------------------------ classify
+// Ray sources: ray `i` of a launch is (o, d) when valid(i)
+struct SoaRays {
+	const float *ox, *oy, *oz, *dx, *dy, *dz;
+	DEV bool valid(uint32_t) const { return true; }
+	DEV void load(uint32_t i, V3& o, V3& d) const { o = mk(ox[i], oy[i], oz[i]); d = mk(dx[i], dy[i], dz[i]); }
+};
+
+template <class Src>
+__global__ void __launch_bounds__(kWfClassifyBlock) k_wf_classify(DevScene S0, Src src, uint32_t n, WfBuffers W, const ModelRec* __restrict__ t_models,
+                                                         const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces,
+                                                         const uint32_t* __restrict__ t_model_space) {
+	DevScene S = S0;
+	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;   // scalar-loaded tables (device_core.hpp: Tables)
+	__shared__ uint32_t s_cnt[kWfMaxSurfaces], s_base[kWfMaxSurfaces], s_wave_total[kWfClassifyBlock / 64];
+	const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+	if (threadIdx.x < (uint32_t)kWfMaxSurfaces) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t i = blockIdx.x * kWfClassifyBlock + threadIdx.x;
+	const bool active = i < n && src.valid(i);
+	V3 o = {0, 0, 0}, d = {0, 0, 1};
+	if (active) src.load(i, o, d);
+
+	// pass 1: the surfaces this ray enters (bit u of `mine`), and per surface the number of rays of this wave that enter it (lane u of `cnt`)
+	unsigned long long mine = 0;
+	uint32_t cnt = 0;
+	{
+		uint32_t cur_space = 0xFFFFFFFFu;
+		V3 lo = o, ld = d, inv = d;
+		for (int m = 0; m < S.n_models; m++) {
+			const ModelRec& M = S.models[m];
+			const uint32_t spc = S.model_space[m];
+			if (spc != cur_space) { to_space(S.spaces[spc], o, d, lo, ld, inv); cur_space = spc; }
+			float nr, fr;
+			const bool enters = active && aabb_test_inv(M.bmin, M.bmax, lo, inv, nr, fr);   // model box first (model.cpp:38-40)
+			if (__ballot(enters) == 0) continue;
+			for (int k = 0; k < M.n_surfaces; k++) {
+				const int u = M.first_surface + k;
+				const SurfaceRec& sf = S.surfaces[u];
+				const bool ent = enters && aabb_test_inv(sf.bmin, sf.bmax, lo, inv, nr, fr);
+				const uint64_t em = __ballot(ent);
+				if (em == 0) continue;
+				if (ent) mine |= 1ull << u;
+				cnt = (int)lane == u ? (uint32_t)__popcll(em) : cnt;
+			}
+		}
+	}
+	// pair slots: the pairs of a ray are consecutive, in surface order. Reservations are made per WORKGROUP (one global atomic per
+	// surface and one for the pair space per 1024 rays): per-wave atomics on two dozen addresses serialise in L2 and cost more than
+	// the box tests (measured: 0.87 ms per 4 M rays with per-wave atomics)
+	const uint32_t mycnt = (uint32_t)__popcll(mine);
+	uint32_t incl = mycnt;
+	for (uint32_t off = 1; off < 64; off <<= 1) {
+		const uint32_t t = __shfl_up(incl, off);
+		if (lane >= off) incl += t;
+	}
+	const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+	uint32_t woff = 0;   // lane u: where this wave's entries start inside the workgroup's reservation of queue u
+	if (cnt) woff = atomicAdd(&s_cnt[lane], cnt);
+	if (lane == 0) s_wave_total[wave] = total;
+	__syncthreads();
+	if (wave == 0) {
+		if (lane < (uint32_t)kWfMaxSurfaces && s_cnt[lane]) s_base[lane] = atomicAdd(&W.ctr[kWfCtrLen + lane], s_cnt[lane]);
+		uint32_t t = lane < (uint32_t)(kWfClassifyBlock / 64) ? s_wave_total[lane] : 0u, ex = t;
+		for (uint32_t off = 1; off < (uint32_t)(kWfClassifyBlock / 64); off <<= 1) {
+			const uint32_t v = __shfl_up(ex, off);
+			if (lane >= off) ex += v;
+		}
+		const uint32_t block_total = __builtin_amdgcn_readlane(ex, kWfClassifyBlock / 64 - 1);
+		uint32_t base = 0;
+		if (lane == 0 && block_total) base = atomicAdd(&W.ctr[0], block_total);
+		base = __builtin_amdgcn_readfirstlane(base);
+		if (lane < (uint32_t)(kWfClassifyBlock / 64)) s_wave_total[lane] = base + ex - t;   // now: first pair of the wave
+	}
+	__syncthreads();
+	const uint32_t first = s_wave_total[wave] + incl - mycnt;
+	if (i < n) { W.first[i] = first; W.mask[i] = mine; }
+	const uint32_t qb = cnt ? s_base[lane] + woff : 0u;
+
+	// pass 2: write the pairs (local ray + surface) and their queue entries
+	{
+		uint32_t cur_space = 0xFFFFFFFFu;
+		V3 lo = o, ld = d, inv = d;
+		for (int m = 0; m < S.n_models; m++) {
+			const ModelRec& M = S.models[m];
+			const unsigned long long range = (M.n_surfaces >= 64 ? ~0ull : ((1ull << M.n_surfaces) - 1ull)) << M.first_surface;
+			if (__ballot((mine & range) != 0) == 0) continue;
+			const uint32_t spc = S.model_space[m];
+			if (spc != cur_space) { to_space(S.spaces[spc], o, d, lo, ld, inv); cur_space = spc; }
+			for (int k = 0; k < M.n_surfaces; k++) {
+				const int u = M.first_surface + k;
+				const bool bit = (mine >> u) & 1ull;
+				const uint64_t em = __ballot(bit);
+				if (em == 0) continue;
+				const uint32_t b = __builtin_amdgcn_readlane(qb, u);
+				if (bit) {
+					const uint32_t p = first + (uint32_t)__popcll(mine & ((1ull << u) - 1ull));
+					W.queue[(size_t)u * W.queue_cap + b + rank_in(em)] = p;
+					W.pair_ray[2 * (size_t)p] = make_float4(lo.x, lo.y, lo.z, __int_as_float(u));
+					W.pair_ray[2 * (size_t)p + 1] = make_float4(ld.x, ld.y, ld.z, 0.f);
+				}
+			}
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------ traverse
+// Visiting order of the queues for a workgroup on XCD x (workgroups are dealt to the 8 XCDs round-robin by blockIdx): first the
+// surfaces u with u % 8 == x, then those of XCD x + 1, ... — while work lasts, every L2 serves its own eighth of the trees.
+DEV int wf_surface_at(uint32_t xcd, uint32_t r, uint32_t n_surf) {
+	// r-th surface in the order above; rows of 8: surfaces {x, x+8, ..}, then {x+1, ..}, ...
+	const uint32_t per = (n_surf + 7u) / 8u;
+	const uint32_t off = r / per, j = r % per;
+	const uint32_t u = ((xcd + off) & 7u) + 8u * j;
+	return u < n_surf ? (int)u : -1;
+}
+
+#ifdef PTX_WF_WAVES
+__attribute__((amdgpu_waves_per_eu(PTX_WF_WAVES, PTX_WF_WAVES)))
+#endif
+__global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers W, const SurfaceRec* __restrict__ t_surfaces) {
+	DevScene S = S0;
+	S.surfaces = t_surfaces;
+	const Geom g = {S.nodes, S.refs, S.tri_isect, S.glb_leaf_ordered != 0, true};
+	__shared__ float4 s_ray[kWfBlock / 64][kWfUnit][2];
+	__shared__ uint32_t s_pair[kWfBlock / 64][kWfUnit];
+	// Pending subtrees beyond the register levels. A store to global memory here would sit in the same in-order counter as the node
+	// fetches (gfx9 has one vmcnt for loads and stores): 4 of 10 node steps on these trees push deeper than the registers hold, and each
+	// would make the next fetch wait for a write acknowledgement. LDS has its own counter and a tenth of the latency.
+	__shared__ uint2 s_stack[kWfLdsStack > 0 ? kWfLdsStack : 1][kWfBlock];
+	const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+	const uint32_t xcd = blockIdx.x & 7u;
+	const Spill spill{W.spill + (size_t)(blockIdx.x * (kWfBlock / 64) + wave) * (kSpillStack * 64) + lane};
+	auto stack_put = [&](int k, uint32_t nn, float mm) {
+		if (k < kWfLdsStack) s_stack[k][threadIdx.x] = make_uint2(nn, __float_as_uint(mm));
+		else spill_put(spill, k - kWfLdsStack, nn, mm);
+	};
+	auto stack_get = [&](int k, uint32_t& nn, float& mm) {
+		if (k < kWfLdsStack) { const uint2 v = s_stack[k][threadIdx.x]; nn = v.x; mm = __uint_as_float(v.y); }
+		else spill_get(spill, k - kWfLdsStack, nn, mm);
+	};
+	const uint32_t n_surf = S.n_surfaces;
+	const uint32_t n_order = ((n_surf + 7u) / 8u) * 8u;
+
+	// wave-uniform: the unit being handed out
+	uint32_t unit_pos = 0, unit_end = 0, unit_base = 0, order_pos = 0, grab_pos = 0, grab_end = 0;
+	const uint32_t stripe0 = (blockIdx.x / 8u) * (kWfBlock / 64) + wave;   // where this wave starts in a queue: the waves of an XCD spread over the stripes
+	int unit_surf = -1;
+	bool more = true;
+	// per lane: the walk in progress (core::mesh::intersect's locals, as in mesh_traverse)
+	bool busy = false, have = false;
+	uint32_t pair = 0, node = 0;
+	int sp = 0;
+	uint32_t n0 = 0, n1 = 0, n2 = 0;
+	float m0 = 0, m1 = 0, m2 = 0;
+	float min_dist = 0, max_dist = 0, fr0 = 0;
+	V3 o = {0, 0, 0}, d = {0, 0, 1};
+#ifdef PTX_WF_PROF
+	uint32_t pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pl[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 outer rounds, 1 busy rounds, 2 node steps, 3 triangle tests, 4 hand-outs, 5 unit fetches, 6 pops
+	uint64_t tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // clocks: 0 whole kernel, 1 unit fetch, 2 hand-out, 3 pop, 4 descend loops, 5 leaf loops, 6 result stores
+	const uint64_t t_start = __builtin_amdgcn_s_memtime();
+#endif
+
+	for (;;) {
+		WFPROF(0);
+		const uint64_t idle_m = __ballot(!busy);
+		if (more && ((uint32_t)__popcll(idle_m) >= kWfRefillMin || ~idle_m == 0)) {
+			if (unit_pos == unit_end) {
+				WFT0();
+				// next unit: the rest of this wave's grab, else a new grab — this XCD's queues first. A queue is handed out in kWfStripes
+				// contiguous stripes, each with its own counter in its own 256 bytes: one counter per queue, two dozen of them in one
+				// cache line, made every hand-out of the chip queue up in one L2 channel (measured: units of 32 / 64 / 128 entries ran at
+				// 656 / 1000 / 1306 Mrays/s). An exhausted stripe is marked in the queue's `done` word and passed over with a plain load.
+				if (grab_pos == grab_end) {
+					for (;;) {
+						if (order_pos >= n_order) { more = false; break; }
+						const int u = wf_surface_at(xcd, order_pos, n_surf);
+						if (u < 0) { order_pos++; continue; }
+						const uint32_t len = __builtin_amdgcn_readfirstlane(W.ctr[kWfCtrLen + u]);
+						const uint32_t slen = ((len + kWfStripes * kWfUnit - 1u) / (kWfStripes * kWfUnit)) * kWfUnit;   // entries per stripe
+						const uint32_t n_str = slen ? (len + slen - 1u) / slen : 0u;
+						uint32_t* sched = W.sched + (size_t)u * (kWfStripes + 1u) * kWfSchedStride;
+						const uint32_t done = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+						int st = -1;
+						for (uint32_t k = 0; k < n_str; k++) {
+							const uint32_t c = (stripe0 + k) % n_str;
+							if (!((done >> c) & 1u)) { st = (int)c; break; }
+						}
+						if (st < 0) { order_pos++; continue; }
+						const uint32_t lo = (uint32_t)st * slen, hi = lo + slen < len ? lo + slen : len;
+						uint32_t b = 0;
+						if (lane == 0) b = atomicAdd(sched + (size_t)(st + 1) * kWfSchedStride, kWfGrab);
+						b = __builtin_amdgcn_readfirstlane(b);
+						if (lo + b >= hi) {
+							if (lane == 0) atomicOr(sched, 1u << st);
+							continue;
+						}
+						unit_surf = u;
+						grab_pos = lo + b;
+						grab_end = grab_pos + kWfGrab < hi ? grab_pos + kWfGrab : hi;
+						break;
+					}
+				}
+				if (more) {
+					unit_pos = unit_base = grab_pos;
+					unit_end = grab_pos + kWfUnit < grab_end ? grab_pos + kWfUnit : grab_end;
+					grab_pos = unit_end;
+				}
+				if (more) {
+					WFPROF(5);
+					// stage the unit's pairs into this wave's LDS slice (coalesced queue read, near-sequential pair reads)
+					for (uint32_t j = lane; j < unit_end - unit_base; j += 64) {
+						const uint32_t p = W.queue[(size_t)unit_surf * W.queue_cap + unit_base + j];
+						s_pair[wave][j] = p;
+						s_ray[wave][j][0] = W.pair_ray[2 * (size_t)p];
+						s_ray[wave][j][1] = W.pair_ray[2 * (size_t)p + 1];
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				}
+				WFT1(1);
+			}
+			if (more) {
+				WFT0();
+				const uint32_t avail = unit_end - unit_pos;
+				const uint32_t r = rank_in(idle_m);
+				if (!busy && r < avail) {
+					WFPROF(4);
+					const uint32_t e = unit_pos - unit_base + r;
+					const float4 e0 = s_ray[wave][e][0], e1 = s_ray[wave][e][1];
+					pair = s_pair[wave][e];
+					o = mk(e0.x, e0.y, e0.z);
+					d = mk(e1.x, e1.y, e1.z);
+					const SurfaceRec& sf = S.surfaces[unit_surf];
+					const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+					float nr, fr;
+					if (aabb_test_inv(sf.bmin, sf.bmax, o, inv, nr, fr)) {   // mesh.cpp:308-315 (the classification saw the same test pass)
+						busy = true; have = true;
+						node = sf.kd_root; min_dist = nr; max_dist = fr; fr0 = fr; sp = 0;
+					} else {
+						W.pair_hit[pair] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+					}
+				}
+				const uint32_t n_idle = (uint32_t)__popcll(idle_m);
+				unit_pos += n_idle < avail ? n_idle : avail;
+				WFT1(2);
+			}
+		}
+		if (__ballot(busy) == 0) {
+			if (!more) break;
+			continue;
+		}
+		// one round of core::mesh::intersect's loop (mesh.cpp:317-403; see mesh_traverse): pop, descend to a leaf, test it
+		{
+			WFT0();
+			if (busy) {
+				WFPROF(1);
+				if (!have) {
+					if (sp == 0) { W.pair_hit[pair] = make_float4(-1.0f, 0.f, 0.f, 0.f); busy = false; }
+					else {
+						WFPROF(6);
+						sp--;
+						node = n0; min_dist = m0;
+						n0 = n1; m0 = m1; n1 = n2; m1 = m2;
+						if (sp >= kRegStack) stack_get(sp - kRegStack, n2, m2);
+						max_dist = sp > 0 ? m0 : fr0;
+					}
+				}
+			}
+			WFT1(3);
+		}
+		bool valid = false;
+		uint2 nd = make_uint2(0, 0);
+		{
+			WFT0();
+			if (busy) {
+				have = false;
+				valid = true;
+				nd = g.nodes[node];
+				while ((nd.y & 3u) != KD_LEAF) {
+					WFPROF(2);
+					const uint32_t axis = nd.y & 3u;
+					const uint2 kid0 = g.nodes[nd.y >> 4], kid1 = g.nodes[(nd.y >> 4) + 1u];   // both children requested with the parent in hand
+					const float split = __uint_as_float(nd.x);
+					const float oa = sel3(o, axis), da = sel3(d, axis);
+#ifdef PTX_WF_ABL_DIV   // sensitivity measurement only: the step's division issued twice (the result is unchanged)
+					float da2 = da;
+					asm volatile("" : "+v"(da2));
+					const float sd2 = (split - oa) / da2;
+					const float sd1 = (split - oa) / da;
+					const float split_dist = sd2 < sd1 ? sd2 : sd1;
+#else
+					const float split_dist = (split - oa) / da;
+#endif
+#ifdef PTX_WF_ABL_LOAD  // sensitivity measurement only: the step's fetch issued twice (second copy: non-temporal flavour of the same address)
+					{
+						typedef uint32_t u4n __attribute__((ext_vector_type(4)));
+						const u4n x = __builtin_nontemporal_load(reinterpret_cast<const u4n*>(g.nodes + (nd.y >> 4)));
+						asm volatile("" :: "v"(x));
+					}
+#endif
+					const bool has_l = nd.y & 4u, has_r = nd.y & 8u;
+					const uint32_t li = nd.y >> 4, ri = li + (has_l ? 1u : 0u);
+					const bool left_first = oa < split;
+					const uint32_t first = left_first ? li : ri, second = left_first ? ri : li;
+					const bool has_first = left_first ? has_l : has_r, has_second = left_first ? has_r : has_l;
+					uint32_t next;
+					bool has_next;
+					if (split_dist < 0 || split_dist > max_dist) { next = first; has_next = has_first; }
+					else if (split_dist < min_dist) { next = second; has_next = has_second; }
+					else {
+						if (has_second && sp < kRegStack + kSpillStack) {
+							if (sp >= kRegStack) { WFPROF(7); stack_put(sp - kRegStack, n2, m2); }
+							n2 = n1; m2 = m1; n1 = n0; m1 = m0; n0 = second; m0 = split_dist;
+							sp++;
+						}
+						next = first; has_next = has_first;
+						max_dist = split_dist;
+					}
+					if (!has_next) { valid = false; break; }
+					node = next;
+					nd = next == li ? kid0 : kid1;
+				}
+			}
+			WFT1(4);
+		}
+		{
+			WFT0();
+			if (busy && valid) {
+				// leaf: nearest triangle with t <= max_dist; ties keep the first (mesh.cpp:381-389)
+				const PRay pr = pack_ray(o, d);
+				const uint32_t first_ref = nd.x, count = nd.y >> 2;
+				float best_t = -1.0f, bb1 = 0, bb2 = 0;
+				uint32_t best_tri = 0;
+				for (uint32_t k = 0; k < count; k++) {
+					WFPROF(3);
+					const uint32_t slot = g.leaf_ordered ? first_ref + k : g.refs[first_ref + k];
+					const float4 r0 = g.tris[3 * slot], r1 = g.tris[3 * slot + 1], r2 = g.tris[3 * slot + 2];
+					const uint32_t ti = __float_as_uint(r2.z);
+					float be, ga;
+					const float t = tri_test_pk(r0, r1, make_float2(r2.x, r2.y), pr, be, ga);
+					if (t >= 0 && t <= max_dist && (t < best_t || !(best_t >= 0))) { best_t = t; bb1 = be; bb2 = ga; best_tri = ti; }
+				}
+				if (best_t >= 0) {
+					W.pair_hit[pair] = make_float4(best_t, __uint_as_float(best_tri), bb1, bb2);
+					busy = false;
+				}
+			}
+			WFT1(5);
+		}
+	}
+#ifdef PTX_WF_PROF
+	for (int k = 0; k < 8; k++) {
+		if (pt[k]) atomicAdd(&W.ctr[kWfCtrProf + 2 * k], pt[k]);
+		if (pl[k]) atomicAdd(&W.ctr[kWfCtrProf + 2 * k + 1], pl[k]);
+	}
+	tc[0] = __builtin_amdgcn_s_memtime() - t_start;
+	if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&W.ctr[kWfCtrProf + 16 + k], (uint32_t)(tc[k] >> 10));
+#endif
+}
+
+// ------------------------------------------------------------------------------------ merge
+// renderer::intersect (core/renderer.cpp:645-671) over scene::model::intersect (scene/model.cpp:20-72) with core::mesh::intersect
+// replaced by the lookup of the pair's result: the loops, comparisons and the local -> world distance are scene_traverse's.
+DEV bool wf_closest(const DevScene& S, const WfBuffers& W, uint32_t i, V3 o, V3 d, SceneHit& best) {
+	best.dist = -1.0f;
+	best.surface = -1;
+	best.tri = 0; best.b1 = 0; best.b2 = 0;
+	const unsigned long long mine = W.mask[i];
+	uint32_t p = W.first[i];
+	uint32_t cur_space = 0xFFFFFFFFu;
+	V3 lo = o, ld = d, inv = d;
+	for (int m = 0; m < S.n_models; m++) {
+		const ModelRec& M = S.models[m];
+		const unsigned long long range = (M.n_surfaces >= 64 ? ~0ull : ((1ull << M.n_surfaces) - 1ull)) << M.first_surface;
+		unsigned long long bits = mine & range;
+		if (__ballot(bits != 0) == 0) continue;
+		const uint32_t spc = S.model_space[m];
+		if (spc != cur_space) { to_space(S.spaces[spc], o, d, lo, ld, inv); cur_space = spc; }
+		MeshHit nearest;
+		nearest.t = -1.0f; nearest.b1 = 0; nearest.b2 = 0; nearest.tri = 0;
+		int hit_surface = -1;
+		while (bits) {
+			const int u = __builtin_ctzll(bits);
+			bits &= bits - 1ull;
+			const float4 h = W.pair_hit[p++];
+			if (!(h.x >= 0)) continue;   // this surface reported no hit
+			if (h.x < nearest.t || !(nearest.t >= 0)) { nearest.t = h.x; nearest.tri = __float_as_uint(h.y); nearest.b1 = h.z; nearest.b2 = h.w; hit_surface = u; }
+		}
+		if (!(nearest.t >= 0)) continue;
+		const float wd = length(mulmv(M.basis, ld * nearest.t));   // local -> world distance (model.cpp:62-63)
+		if (!(wd >= 0)) continue;
+		if (wd < best.dist || !(best.dist >= 0)) { best.dist = wd; best.surface = hit_surface; best.tri = nearest.tri; best.b1 = nearest.b1; best.b2 = nearest.b2; }
+	}
+	return best.surface >= 0;
+}
+
+__global__ void __launch_bounds__(kWfBlock) k_wf_merge_batch(DevScene S0, IntersectArgs A, size_t first_ray, uint32_t n, WfBuffers W, const ModelRec* __restrict__ t_models,
+                                                            const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces,
+                                                            const uint32_t* __restrict__ t_model_space) {
+	DevScene S = S0;
+	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;
+	const uint32_t i = blockIdx.x * kWfBlock + threadIdx.x;
+	if (i >= n) return;
+	const size_t gi = first_ray + i;
+	const V3 o = mk(A.ox[gi], A.oy[gi], A.oz[gi]), d = mk(A.dx[gi], A.dy[gi], A.dz[gi]);
+	SceneHit h;
+	const bool hit = wf_closest(S, W, i, o, d, h);
+	write_hit_outputs(S, S.shade, A, gi, hit, h);
+}
+
+// ------------------------------------------------------------------------------------ launchers
+hipError_t launch_wf_intersect(const DevScene& S, const IntersectArgs& A, size_t first_ray, uint32_t n, const WfBuffers& W, int n_cu, hipStream_t stream) {
+	const SoaRays src{A.ox + first_ray, A.oy + first_ray, A.oz + first_ray, A.dx + first_ray, A.dy + first_ray, A.dz + first_ray};
+	const dim3 grid((n + kWfBlock - 1) / kWfBlock), block(kWfBlock);
+	hipError_t e = hipMemsetAsync(W.ctr, 0, kWfCtrBytes, stream);
+	if (e != hipSuccess) return e;
+	e = hipMemsetAsync(W.sched, 0, wf_sched_bytes(S.n_surfaces), stream);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k_wf_classify<SoaRays>, dim3((n + kWfClassifyBlock - 1) / kWfClassifyBlock), dim3(kWfClassifyBlock), 0, stream, S, src, n, W, S.models, S.surfaces, S.spaces, S.model_space);
+	hipLaunchKernelGGL(k_wf_traverse, dim3(wf_traverse_grid(n_cu)), block, 0, stream, S, W, S.surfaces);
+	hipLaunchKernelGGL(k_wf_merge_batch, grid, block, 0, stream, S, A, first_ray, n, W, S.models, S.surfaces, S.spaces, S.model_space);
+	return hipGetLastError();
+}
+
+}  // namespace ptx
