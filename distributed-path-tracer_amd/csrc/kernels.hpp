@@ -116,12 +116,24 @@ struct WfBuffers {
 	uint32_t* ctr;                 // counters block, zeroed per launch (wavefront.hip: kWfCtr*)
 	uint32_t* sched;               // [n_surfaces][1 + kWfStripes][kWfSchedStride]: per queue a `done` word and one hand-out counter per stripe, 256 bytes apart; zeroed per launch
 	uint2* spill;                  // [wf_traverse_grid * 4 waves][kSpillWords]
+	unsigned long long* ray_counter;   // nullptr, or where classify adds the number of rays it was given (render statistics)
 };
+// One of the two path-stream buffers of a render slab (SoA of float4, `cap` entries per array)
+struct WfStream {
+	float4* q;   // [4][cap]: (origin, id | flags) (direction, T.x) (T.y, T.z, L.x, L.y) (L.z, depth << 16 | pass, RNG key pixel, RNG key sample) — the fused kernel's entry
+	float4* r;   // [3][cap]: the entry's shadow request: (origin, -) (direction, -) (x: radiance to add when unoccluded | origin of a shadow catcher's pass-through ray, -)
+};
+// flags in the id word of a stream entry (ids are slab-local, < 2^24)
+constexpr uint32_t kWfIdMask = 0x00FFFFFFu, kWfZombie = 1u << 31, kWfPending = 1u << 30, kWfRequest = 1u << 29;
+constexpr uint32_t kWfMaxSlab = 1u << 24;
 constexpr size_t kWfCtrBytes = 192 * 4;   // [0] pairs, [64 + u] queue lengths, [128 + u] hand-out positions, [160 ..] PTX_WF_PROF region counters
 constexpr uint32_t kWfStripes = 16, kWfSchedStride = 64;
 inline size_t wf_sched_bytes(size_t n_surf) { return n_surf * (kWfStripes + 1u) * kWfSchedStride * 4; }
 constexpr int kWfMaxSurfaces = 64;   // surface masks are one 64-bit word
 inline int wf_traverse_grid(int n_cu) { return n_cu * 8; }   // 256-thread workgroups, 8 per CU = 8 waves per SIMD
+hipError_t launch_wf_generate(const DevScene& S, const RenderParams& P, const WfStream& out, uint32_t cap, uint32_t first, uint32_t n, float4* sample_rad, hipStream_t stream);
+hipError_t launch_wf_step(const DevScene& S, const RenderParams& P, const WfBuffers& W, const WfStream& in, const WfStream& out, uint32_t cap, uint32_t n_in,
+                          uint32_t slab_first, uint32_t* n_out, float4* sample_rad, int n_cu, hipStream_t stream);
 hipError_t launch_wf_intersect(const DevScene& S, const IntersectArgs& A, size_t first_ray, uint32_t n, const WfBuffers& W, int n_cu, hipStream_t stream);
 
 hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, int mode, size_t lds_bytes, int grid,

@@ -82,7 +82,8 @@ struct ptx_ctx {
 	int n_cu = 0;
 	std::mutex mu;
 	DevBuf queues, sample_rad, counters, spill, stage_a, stage_b, pixel_list, srgb_thr;
-	DevBuf wf_pair_ray, wf_pair_hit, wf_queue, wf_first, wf_mask, wf_ctr, wf_sched, wf_spill;   // workspace of the queue-based pipeline (wavefront.hip)
+	DevBuf wf_pair_ray, wf_pair_hit, wf_queue, wf_first, wf_mask, wf_ctr, wf_sched, wf_spill, wf_stream, wf_flow;
+	uint32_t* wf_flow_host = nullptr;   // pinned: entries the last step wrote   // workspace of the queue-based pipeline (wavefront.hip)
 	std::vector<hipEvent_t> events;
 	// pixel list of the last sharded render (ptx_render_cfg::shard_*), kept on the device: a frame is usually rendered again
 	// with the same sharding (sample ranges, benchmark steps)
@@ -264,7 +265,8 @@ static void ctx_release(ptx_ctx* c) {
 	(void)hipStreamSynchronize(c->stream);
 	for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
 	c->queues.release(); c->spill.release(); c->sample_rad.release(); c->counters.release(); c->stage_a.release(); c->stage_b.release(); c->pixel_list.release(); c->srgb_thr.release();
-	c->wf_pair_ray.release(); c->wf_pair_hit.release(); c->wf_queue.release(); c->wf_first.release(); c->wf_mask.release(); c->wf_ctr.release(); c->wf_sched.release(); c->wf_spill.release();
+	c->wf_pair_ray.release(); c->wf_pair_hit.release(); c->wf_queue.release(); c->wf_first.release(); c->wf_mask.release(); c->wf_ctr.release(); c->wf_sched.release(); c->wf_spill.release(); c->wf_stream.release(); c->wf_flow.release();
+	if (c->wf_flow_host) { (void)hipHostFree(c->wf_flow_host); c->wf_flow_host = nullptr; }
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -496,13 +498,15 @@ namespace {
 
 // Scenes the queue-based pipeline (wavefront.hip) takes: trees in global memory, a model of many surfaces (where the fused kernel's
 // waves run nearly empty), at most 64 surfaces (one mask word per ray). PTX_WAVEFRONT=0/1 overrides the choice (measurement).
-constexpr size_t kWfMaxPairs = 96u << 20;   // pairs the workspace is sized for: 48 B each + 4 B of queue
+constexpr size_t kWfMaxPairs = 96u << 20;   // pairs the workspace of a batch-intersect slice is sized for: 48 B each + 4 B of queue
+constexpr uint64_t kWfRenderPairs = 384ull << 20;   // ... of a render slab (20 GB; the device has 288)
 bool use_wavefront(const ptx_scene* sc) {
 	const size_t n_surf = sc->host.surfaces.size();
 	if (n_surf == 0 || n_surf > (size_t)kWfMaxSurfaces) return false;
 	int32_t max_per_model = 0;
 	for (const ModelRec& mr : sc->host.models) max_per_model = std::max(max_per_model, mr.n_surfaces);
-	bool on = max_per_model >= 8 && sc->mode != MODE_LDS;
+	if (sc->mode == MODE_LDS || !sc->dev.tri_isect) return false;   // LDS-resident scenes keep no global-memory copy of the traversal records
+	bool on = max_per_model >= 8;
 	if (const char* e = getenv("PTX_WAVEFRONT")) on = e[0] == '1';
 	return on;
 }
@@ -591,7 +595,8 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 	bool surface_units = max_per_model >= 8 && n_surf <= (uint32_t)kMaxDeferModels;   // measured: +49 % on a 24-surface model, -2..-7 % on scenes of 1-3 surfaces per model
 	if (const char* e = getenv("PTX_SURFACE_UNITS")) surface_units = e[0] == '1' && n_surf <= (uint32_t)kMaxDeferModels;
 	const uint32_t queue_stride = queue_float4_per_wave(surface_units ? n_surf : n_mod);
-	HIP_TRY(c->queues.ensure(n_slots * (size_t)queue_stride * sizeof(float4)));
+	const bool wavefront = use_wavefront(sc);
+	if (!wavefront) HIP_TRY(c->queues.ensure(n_slots * (size_t)queue_stride * sizeof(float4)));
 	HIP_TRY(c->sample_rad.ensure((size_t)pass_spp * n_pixels * sizeof(float4)));
 	HIP_TRY(c->counters.ensure(1024));   // [0] chunk counter, [16] ray counter, [64..] PTX_PROF region counters
 	HIP_TRY(c->spill.ensure(n_slots * (size_t)kSpillWords * sizeof(uint2)));
@@ -615,6 +620,22 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 			c->events.push_back(ev);
 		}
 	PassBuffers B{(float4*)c->queues.p, queue_stride, surface_units ? 1u : 0u, (float4*)c->sample_rad.p, (uint2*)c->spill.p, chunk_counter, ray_counter};
+	// queue-based pipeline (wavefront.hip): slab size from the pair budget — a step classifies two rays per path (extend + shadow)
+	WfBuffers WF{};
+	WfStream wf_st[2]{};
+	uint32_t wf_cap = 0;
+	if (wavefront) {
+		const uint64_t pass_paths = (uint64_t)pass_spp * n_pixels;
+		wf_cap = (uint32_t)std::min<uint64_t>({pass_paths, (uint64_t)kWfMaxSlab, std::max<uint64_t>(65536, kWfRenderPairs / (2 * (uint64_t)n_surf))});
+		HIP_TRY(wf_workspace(c, 2 * (size_t)wf_cap, n_surf, WF));
+		WF.ray_counter = ray_counter;
+		HIP_TRY(c->wf_stream.ensure((size_t)wf_cap * 14 * sizeof(float4)));
+		HIP_TRY(c->wf_flow.ensure(64));
+		if (!c->wf_flow_host) HIP_TRY(hipHostMalloc((void**)&c->wf_flow_host, 64));
+		float4* base = (float4*)c->wf_stream.p;
+		wf_st[0] = WfStream{base, base + 8 * (size_t)wf_cap};
+		wf_st[1] = WfStream{base + 4 * (size_t)wf_cap, base + 11 * (size_t)wf_cap};
+	}
 	for (uint32_t p = 0; p < n_pass; p++) {
 		RenderParams P{};
 		P.W = cfg->W; P.H = cfg->H; P.x0 = x0; P.y0 = y0; P.w = w; P.h = h;
@@ -629,7 +650,21 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 		P.pixels = d_pixels;
 		HIP_TRY(hipMemsetAsync(chunk_counter, 0, 8, c->stream));
 		if (stats) HIP_TRY(hipEventRecord(c->events[2 * p], c->stream));
-		HIP_TRY(launch_render_pass(sc->dev, P, B, sc->mode, sc->lds_bytes, grid, c->stream));
+		if (wavefront) {
+			// queue-based pipeline: the pass in slabs of at most `wf_cap` paths, each advanced step by step until no path is left
+			for (uint64_t first = 0; first < P.n_paths; first += wf_cap) {
+				uint32_t n_in = (uint32_t)std::min<uint64_t>(wf_cap, P.n_paths - first);
+				HIP_TRY(launch_wf_generate(sc->dev, P, wf_st[0], wf_cap, (uint32_t)first, n_in, B.sample_rad, c->stream));
+				if (P.bounces == 0) continue;
+				for (int cur = 0; n_in > 0; cur ^= 1) {
+					HIP_TRY(launch_wf_step(sc->dev, P, WF, wf_st[cur], wf_st[cur ^ 1], wf_cap, n_in, (uint32_t)first, (uint32_t*)c->wf_flow.p, B.sample_rad, c->n_cu, c->stream));
+					HIP_TRY(hipMemcpyAsync(c->wf_flow_host, c->wf_flow.p, 4, hipMemcpyDeviceToHost, c->stream));
+					HIP_TRY(hipStreamSynchronize(c->stream));
+					n_in = *c->wf_flow_host;
+				}
+			}
+		} else
+			HIP_TRY(launch_render_pass(sc->dev, P, B, sc->mode, sc->lds_bytes, grid, c->stream));
 		if (stats) HIP_TRY(hipEventRecord(c->events[2 * p + 1], c->stream));
 		HIP_TRY(launch_resolve(B.sample_rad, d_accum, d_pixels, P.n_pixels, P.pass_spp, c->stream));
 	}

@@ -81,7 +81,9 @@ __global__ void __launch_bounds__(kWfClassifyBlock) k_wf_classify(DevScene S0, S
 	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;   // scalar-loaded tables (device_core.hpp: Tables)
 	__shared__ uint32_t s_cnt[kWfMaxSurfaces], s_base[kWfMaxSurfaces], s_wave_total[kWfClassifyBlock / 64];
 	const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+	__shared__ uint32_t s_rays;
 	if (threadIdx.x < (uint32_t)kWfMaxSurfaces) s_cnt[threadIdx.x] = 0;
+	if (threadIdx.x == 0) s_rays = 0;
 	__syncthreads();
 	const uint32_t i = blockIdx.x * kWfClassifyBlock + threadIdx.x;
 	const bool active = i < n && src.valid(i);
@@ -125,7 +127,12 @@ __global__ void __launch_bounds__(kWfClassifyBlock) k_wf_classify(DevScene S0, S
 	uint32_t woff = 0;   // lane u: where this wave's entries start inside the workgroup's reservation of queue u
 	if (cnt) woff = atomicAdd(&s_cnt[lane], cnt);
 	if (lane == 0) s_wave_total[wave] = total;
+	if (W.ray_counter) {   // rays traced (stats): one atomic per workgroup
+		const uint32_t nv = (uint32_t)__popcll(__ballot(active));
+		if (lane == 0 && nv) atomicAdd(&s_rays, nv);
+	}
 	__syncthreads();
+	if (W.ray_counter && threadIdx.x == 0 && s_rays) atomicAdd(W.ray_counter, (unsigned long long)s_rays);
 	if (wave == 0) {
 		if (lane < (uint32_t)kWfMaxSurfaces && s_cnt[lane]) s_base[lane] = atomicAdd(&W.ctr[kWfCtrLen + lane], s_cnt[lane]);
 		uint32_t t = lane < (uint32_t)(kWfClassifyBlock / 64) ? s_wave_total[lane] : 0u, ex = t;
@@ -476,6 +483,151 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_merge_batch(DevScene S0, Inters
 	write_hit_outputs(S, S.shade, A, gi, hit, h);
 }
 
+
+// ------------------------------------------------------------------------------------ integrator on queues
+// The path stream of a render slab: SoA of float4, the fused kernel's stream entry plus flags in the id word, and the entry's shadow
+// request beside it (kernels.hpp: WfStream). One STEP = classify (the extend ray and the shadow ray of every entry) -> traverse ->
+// shade (this file's k_wf_shade: the answer to the entry's shadow request, closest hit, one path vertex, next entry).
+DEV uint32_t wf_id(float4 q0) { return __float_as_uint(q0.w) & kWfIdMask; }
+DEV uint32_t wf_flags(float4 q0) { return __float_as_uint(q0.w) & ~kWfIdMask; }
+
+// ray t of a step: t < n_in: the extend ray of entry t (entries that wait for a shadow answer have none); else the shadow ray of entry t - n_in
+struct StreamRays {
+	const float4* q;   // [4][cap]
+	const float4* r;   // [3][cap]
+	uint32_t cap, n_in;
+	DEV bool valid(uint32_t t) const {
+		const uint32_t i = t < n_in ? t : t - n_in;
+		const uint32_t f = wf_flags(q[i]);
+		return t < n_in ? !(f & (kWfZombie | kWfPending)) : (f & kWfRequest) != 0;
+	}
+	DEV void load(uint32_t t, V3& o, V3& d) const {
+		if (t < n_in) { const float4 a = q[t], b = q[cap + t]; o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); }
+		else { const uint32_t i = t - n_in; const float4 a = r[i], b = r[cap + i]; o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); }
+	}
+};
+
+// camera paths [first, first + n) of the pass -> stream entries 0 .. n-1 (scene::camera::get_ray; renderer.cpp:359-370)
+__global__ void __launch_bounds__(kWfBlock) k_wf_generate(DevScene S, RenderParams P, WfStream out, uint32_t cap, uint32_t first, uint32_t n, float4* __restrict__ sample_rad) {
+	const uint32_t i = blockIdx.x * kWfBlock + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t id = first + i;   // id within the pass: sample-major, pixel-minor
+	if (P.bounces == 0) { sample_rad[id] = make_float4(0.f, 0.f, 0.f, 1.0f); return; }   // trace(0, ..) is black with alpha 1 (renderer.cpp:438-439)
+	const uint32_t s_local = id / P.n_pixels;
+	uint32_t p_local = id - s_local * P.n_pixels;
+	if (P.pixels) p_local = P.pixels[p_local];
+	const uint32_t px = P.x0 + p_local % P.w, py = P.y0 + p_local / P.w;
+	V3 o, d;
+	camera_ray(S, P, px, py, P.sample0 + s_local, o, d);
+	out.q[i] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
+	out.q[cap + i] = make_float4(d.x, d.y, d.z, 1.0f);
+	out.q[2 * (size_t)cap + i] = make_float4(1.0f, 1.0f, 0.f, 0.f);
+	out.q[3 * (size_t)cap + i] = make_float4(0.f, __uint_as_float(0u), __uint_as_float(py * P.W + px), __uint_as_float(P.sample0 + s_local));
+}
+
+// renderer::intersect(shadow ray).has_hit() (renderer.cpp:509-511, intersection_worker.cpp:58-61) from the pair results: some surface
+// reports a hit whose world distance is not NaN (scene_occluded's test)
+DEV bool wf_any(const DevScene& S, const WfBuffers& W, uint32_t i, V3 o, V3 d) {
+	const unsigned long long mine = W.mask[i];
+	uint32_t p = W.first[i];
+	uint32_t cur_space = 0xFFFFFFFFu;
+	V3 lo = o, ld = d, inv = d;
+	bool occ = false;
+	for (int m = 0; m < S.n_models; m++) {
+		const ModelRec& M = S.models[m];
+		const unsigned long long range = (M.n_surfaces >= 64 ? ~0ull : ((1ull << M.n_surfaces) - 1ull)) << M.first_surface;
+		unsigned long long bits = mine & range;
+		if (__ballot(bits != 0) == 0) continue;
+		const uint32_t spc = S.model_space[m];
+		if (spc != cur_space) { to_space(S.spaces[spc], o, d, lo, ld, inv); cur_space = spc; }
+		while (bits) {
+			bits &= bits - 1ull;
+			const float4 h = W.pair_hit[p++];
+			if (h.x >= 0 && length(mulmv(M.basis, ld * h.x)) >= 0) occ = true;
+		}
+	}
+	return occ;
+}
+
+// One step of every path of the stream: what the fused kernel does in its SHADOW sweep of the previous step (the answer to the entry's
+// shadow request: the sun's contribution, or the fate of a shadow catcher) and in its SHADE sweep of this one (shade_vertex), with
+// the survivors appended to the other stream buffer. 256-thread workgroups: no 128-register cap, nothing spills.
+template <bool SUN, bool ALPHA, bool TEX, bool WORKER>
+__global__ void __launch_bounds__(kWfBlock) k_wf_shade(DevScene S0, RenderParams P, WfBuffers W, WfStream in, WfStream out, uint32_t cap, uint32_t n_in, uint32_t slab_first,
+                                                      uint32_t* __restrict__ n_out, float4* __restrict__ sample_rad, const ModelRec* __restrict__ t_models,
+                                                      const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
+	DevScene S = S0;
+	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;
+	__shared__ uint32_t s_wave_n[kWfBlock / 64];
+	const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+	const uint32_t i = blockIdx.x * kWfBlock + threadIdx.x;
+	V3 o = {0, 0, 0}, d = {0, 0, 1}, T = {1, 1, 1}, L = {0, 0, 0};
+	uint32_t id = 0, depth = 0, pass = 0, out_flags = 0;
+	float key_px = 0.f, key_s = 0.f;
+	bool emit = false;
+	ShadowReq rq;
+	rq.kind = REQ_NONE;
+	if (i < n_in) {
+		const float4 q0 = in.q[i], q1 = in.q[cap + i], q2 = in.q[2 * (size_t)cap + i], q3 = in.q[3 * (size_t)cap + i];
+		o = mk(q0.x, q0.y, q0.z); id = wf_id(q0);
+		const uint32_t flags = wf_flags(q0);
+		d = mk(q1.x, q1.y, q1.z);
+		T = mk(q1.w, q2.x, q2.y);
+		L = mk(q2.z, q2.w, q3.x);
+		key_px = q3.z; key_s = q3.w;
+		{ const uint32_t dp = __float_as_uint(q3.y); depth = dp >> 16; pass = dp & 0xFFFFu; }
+		float4* const result = sample_rad + slab_first + id;
+		bool occluded = false;
+		V3 x = {0, 0, 0};
+		if (flags & kWfRequest) {
+			const float4 r0 = in.r[i], r1 = in.r[cap + i], r2 = in.r[2 * (size_t)cap + i];
+			x = mk(r2.x, r2.y, r2.z);
+			occluded = wf_any(S, W, n_in + i, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z));
+		}
+		if (flags & kWfPending) {
+			// shadow catcher (renderer.cpp:513-519, 560-561; shading_worker.cpp:74-104): shadowed -> the path ends (trace() returns what it has,
+			// the worker zeroes the colour); lit -> fully transparent: same depth, next pass, continued from behind the surface (x)
+			if (occluded) *result = WORKER ? make_float4(0.f, 0.f, 0.f, 1.0f) : make_float4(L.x, L.y, L.z, 1.0f);
+			else if (pass + 1u > 4096u) *result = make_float4(L.x, L.y, L.z, 1.0f);
+			else { o = x; d = normalize(d); pass++; emit = true; }
+		} else {
+			if ((flags & kWfRequest) && !occluded) L = mk(L.x + x.x, L.y + x.y, L.z + x.z);   // the sun's contribution of the previous vertex
+			if (flags & kWfZombie) *result = make_float4(L.x, L.y, L.z, 1.0f);
+			else {
+				SceneHit h;
+				wf_closest(S, W, i, o, d, h);
+				const int state = shade_vertex<SUN, ALPHA, TEX, WORKER>(S, S.shade, P, __float_as_uint(key_px), __float_as_uint(key_s), depth, pass, h, o, d, T, L, rq);
+				if (state == V_ALIVE) emit = true;
+				else if (state == V_PENDING) { emit = true; out_flags = kWfPending; o = rq.x; }
+				else if (rq.kind == REQ_ADD) { emit = true; out_flags = kWfZombie; }   // the path is over, its last sun sample is not
+				else *result = make_float4(L.x, L.y, L.z, 1.0f);
+				if (rq.kind != REQ_NONE) out_flags |= kWfRequest;
+			}
+		}
+	}
+	// survivors -> the other buffer: wave ballot + prefix, one counter fetch per workgroup
+	const uint64_t em = __ballot(emit);
+	if (lane == 0) s_wave_n[wave] = (uint32_t)__popcll(em);
+	__syncthreads();
+	uint32_t before = 0, total = 0;
+	for (uint32_t w = 0; w < (uint32_t)(kWfBlock / 64); w++) { const uint32_t c = s_wave_n[w]; if (w < wave) before += c; total += c; }
+	__syncthreads();
+	if (threadIdx.x == 0) s_wave_n[0] = total ? atomicAdd(n_out, total) : 0u;
+	__syncthreads();
+	if (emit) {
+		const uint32_t pos = s_wave_n[0] + before + rank_in(em);
+		out.q[pos] = make_float4(o.x, o.y, o.z, __uint_as_float(id | out_flags));
+		out.q[cap + pos] = make_float4(d.x, d.y, d.z, T.x);
+		out.q[2 * (size_t)cap + pos] = make_float4(T.y, T.z, L.x, L.y);
+		out.q[3 * (size_t)cap + pos] = make_float4(L.z, __uint_as_float((depth << 16) | pass), key_px, key_s);
+		if (out_flags & kWfRequest) {
+			out.r[pos] = make_float4(rq.o.x, rq.o.y, rq.o.z, 0.f);
+			out.r[cap + pos] = make_float4(rq.d.x, rq.d.y, rq.d.z, 0.f);
+			out.r[2 * (size_t)cap + pos] = make_float4(rq.x.x, rq.x.y, rq.x.z, 0.f);
+		}
+	}
+}
+
 // ------------------------------------------------------------------------------------ launchers
 hipError_t launch_wf_intersect(const DevScene& S, const IntersectArgs& A, size_t first_ray, uint32_t n, const WfBuffers& W, int n_cu, hipStream_t stream) {
 	const SoaRays src{A.ox + first_ray, A.oy + first_ray, A.oz + first_ray, A.dx + first_ray, A.dy + first_ray, A.dz + first_ray};
@@ -487,6 +639,41 @@ hipError_t launch_wf_intersect(const DevScene& S, const IntersectArgs& A, size_t
 	hipLaunchKernelGGL(k_wf_classify<SoaRays>, dim3((n + kWfClassifyBlock - 1) / kWfClassifyBlock), dim3(kWfClassifyBlock), 0, stream, S, src, n, W, S.models, S.surfaces, S.spaces, S.model_space);
 	hipLaunchKernelGGL(k_wf_traverse, dim3(wf_traverse_grid(n_cu)), block, 0, stream, S, W, S.surfaces);
 	hipLaunchKernelGGL(k_wf_merge_batch, grid, block, 0, stream, S, A, first_ray, n, W, S.models, S.surfaces, S.spaces, S.model_space);
+	return hipGetLastError();
+}
+
+hipError_t launch_wf_generate(const DevScene& S, const RenderParams& P, const WfStream& out, uint32_t cap, uint32_t first, uint32_t n, float4* sample_rad, hipStream_t stream) {
+	hipLaunchKernelGGL(k_wf_generate, dim3((n + kWfBlock - 1) / kWfBlock), dim3(kWfBlock), 0, stream, S, P, out, cap, first, n, sample_rad);
+	return hipGetLastError();
+}
+
+template <bool SUN, bool ALPHA, bool TEX, bool WORKER>
+static void launch_shade_variant(const DevScene& S, const RenderParams& P, const WfBuffers& W, const WfStream& in, const WfStream& out, uint32_t cap, uint32_t n_in,
+                                 uint32_t slab_first, uint32_t* n_out, float4* sample_rad, hipStream_t stream) {
+	hipLaunchKernelGGL((k_wf_shade<SUN, ALPHA, TEX, WORKER>), dim3((n_in + kWfBlock - 1) / kWfBlock), dim3(kWfBlock), 0, stream, S, P, W, in, out, cap, n_in, slab_first, n_out,
+	                   sample_rad, S.models, S.surfaces, S.spaces, S.model_space);
+}
+
+// One step of a slab: rays of the `n_in` entries of `in` (extend + shadow) through the queues, then one vertex per path into `out`;
+// *n_out (device) receives the number of entries written. Kernel variants as in the fused integrator (launch_pass_mode).
+hipError_t launch_wf_step(const DevScene& S, const RenderParams& P, const WfBuffers& W, const WfStream& in, const WfStream& out, uint32_t cap, uint32_t n_in,
+                          uint32_t slab_first, uint32_t* n_out, float4* sample_rad, int n_cu, hipStream_t stream) {
+	hipError_t e = hipMemsetAsync(W.ctr, 0, kWfCtrBytes, stream);
+	if (e != hipSuccess) return e;
+	if ((e = hipMemsetAsync(W.sched, 0, wf_sched_bytes(S.n_surfaces), stream)) != hipSuccess) return e;
+	if ((e = hipMemsetAsync(n_out, 0, 4, stream)) != hipSuccess) return e;
+	const StreamRays src{in.q, in.r, cap, n_in};
+	const uint32_t n_rays = 2u * n_in;
+	hipLaunchKernelGGL(k_wf_classify<StreamRays>, dim3((n_rays + kWfClassifyBlock - 1) / kWfClassifyBlock), dim3(kWfClassifyBlock), 0, stream, S, src, n_rays, W, S.models, S.surfaces,
+	                   S.spaces, S.model_space);
+	hipLaunchKernelGGL(k_wf_traverse, dim3(wf_traverse_grid(n_cu)), dim3(kWfBlock), 0, stream, S, W, S.surfaces);
+	const bool sun = S.sun.present != 0, alpha = S.any_alpha != 0;
+#define WF_SHADE(SUN_, ALPHA_, TEX_, WORKER_) launch_shade_variant<SUN_, ALPHA_, TEX_, WORKER_>(S, P, W, in, out, cap, n_in, slab_first, n_out, sample_rad, stream)
+	if (P.integrator == 1u) { if (S.any_texture) WF_SHADE(true, true, true, true); else WF_SHADE(true, true, false, true); }
+	else if (S.any_texture) WF_SHADE(true, true, true, false);
+	else if (sun) { if (alpha) WF_SHADE(true, true, false, false); else WF_SHADE(true, false, false, false); }
+	else { if (alpha) WF_SHADE(false, true, false, false); else WF_SHADE(false, false, false, false); }
+#undef WF_SHADE
 	return hipGetLastError();
 }
 
