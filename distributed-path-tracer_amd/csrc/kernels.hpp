@@ -114,7 +114,7 @@ struct WfBuffers {
 	uint32_t* first;               // [rays] first pair of the ray
 	unsigned long long* mask;      // [rays] bit u: the ray enters surface u
 	uint32_t* ctr;                 // counters block, zeroed per launch (wavefront.hip: kWfCtr*)
-	uint32_t* sched;               // [n_surfaces][1 + kWfStripes][kWfSchedStride]: per queue a `done` word and one hand-out counter per stripe, 256 bytes apart; zeroed per launch
+	uint32_t* sched;               // [n_surfaces][1 + kWfStripes][kWfSchedStride]: per queue one hand-out counter per stripe (slot 1 ..), 256 bytes apart; zeroed per launch
 	uint2* spill;                  // [wf_traverse_grid * 4 waves][kSpillWords]
 	unsigned long long* ray_counter;   // nullptr, or where classify adds the number of rays it was given (render statistics)
 };
@@ -130,7 +130,7 @@ constexpr size_t kWfCtrBytes = 192 * 4;   // [0] pairs, [64 + u] queue lengths, 
 constexpr uint32_t kWfStripes = 16, kWfSchedStride = 64;
 inline size_t wf_sched_bytes(size_t n_surf) { return n_surf * (kWfStripes + 1u) * kWfSchedStride * 4; }
 constexpr int kWfMaxSurfaces = 64;   // surface masks are one 64-bit word
-inline int wf_traverse_grid(int n_cu) { return n_cu * 8; }   // 256-thread workgroups, 8 per CU = 8 waves per SIMD
+inline int wf_traverse_grid(int n_cu) { return n_cu * 8; }   // persistent 256-thread workgroups: as many as can be resident (8 waves per SIMD at most)
 hipError_t launch_wf_generate(const DevScene& S, const RenderParams& P, const WfStream& out, uint32_t cap, uint32_t first, uint32_t n, float4* sample_rad, hipStream_t stream);
 hipError_t launch_wf_step(const DevScene& S, const RenderParams& P, const WfBuffers& W, const WfStream& in, const WfStream& out, uint32_t cap, uint32_t n_in,
                           uint32_t slab_first, uint32_t* n_out, float4* sample_rad, int n_cu, hipStream_t stream);

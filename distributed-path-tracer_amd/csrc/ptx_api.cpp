@@ -82,8 +82,16 @@ struct ptx_ctx {
 	int n_cu = 0;
 	std::mutex mu;
 	DevBuf queues, sample_rad, counters, spill, stage_a, stage_b, pixel_list, srgb_thr;
-	DevBuf wf_pair_ray, wf_pair_hit, wf_queue, wf_first, wf_mask, wf_ctr, wf_sched, wf_spill, wf_stream, wf_flow;
-	uint32_t* wf_flow_host = nullptr;   // pinned: entries the last step wrote   // workspace of the queue-based pipeline (wavefront.hip)
+	// workspace of the queue-based pipeline (wavefront.hip). A render advances two slabs of paths side by side, each on its own stream with
+	// its own set: the end of one slab's traverse kernel (a few waves finishing walks of hundreds of dependent fetches) and the host's
+	// wait for its entry count then run under the other slab's kernels. ptx_intersect_batch uses set 0 on the context's stream.
+	struct WfSet {
+		DevBuf pair_ray, pair_hit, queue, first, mask, ctr, sched, spill, stream_buf, flow;
+		uint32_t* flow_host = nullptr;   // pinned: entries the last step wrote
+		hipStream_t stream = nullptr;
+		hipEvent_t done = nullptr;
+	} wf[2];
+	hipEvent_t wf_main_ev = nullptr;
 	std::vector<hipEvent_t> events;
 	// pixel list of the last sharded render (ptx_render_cfg::shard_*), kept on the device: a frame is usually rendered again
 	// with the same sharding (sample ranges, benchmark steps)
@@ -265,8 +273,13 @@ static void ctx_release(ptx_ctx* c) {
 	(void)hipStreamSynchronize(c->stream);
 	for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
 	c->queues.release(); c->spill.release(); c->sample_rad.release(); c->counters.release(); c->stage_a.release(); c->stage_b.release(); c->pixel_list.release(); c->srgb_thr.release();
-	c->wf_pair_ray.release(); c->wf_pair_hit.release(); c->wf_queue.release(); c->wf_first.release(); c->wf_mask.release(); c->wf_ctr.release(); c->wf_sched.release(); c->wf_spill.release(); c->wf_stream.release(); c->wf_flow.release();
-	if (c->wf_flow_host) { (void)hipHostFree(c->wf_flow_host); c->wf_flow_host = nullptr; }
+	for (auto& w : c->wf) {
+		for (DevBuf* b : {&w.pair_ray, &w.pair_hit, &w.queue, &w.first, &w.mask, &w.ctr, &w.sched, &w.spill, &w.stream_buf, &w.flow}) b->release();
+		if (w.flow_host) { (void)hipHostFree(w.flow_host); w.flow_host = nullptr; }
+		if (w.done) { (void)hipEventDestroy(w.done); w.done = nullptr; }
+		if (w.stream) { (void)hipStreamDestroy(w.stream); w.stream = nullptr; }
+	}
+	if (c->wf_main_ev) { (void)hipEventDestroy(c->wf_main_ev); c->wf_main_ev = nullptr; }
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -499,7 +512,8 @@ namespace {
 // Scenes the queue-based pipeline (wavefront.hip) takes: trees in global memory, a model of many surfaces (where the fused kernel's
 // waves run nearly empty), at most 64 surfaces (one mask word per ray). PTX_WAVEFRONT=0/1 overrides the choice (measurement).
 constexpr size_t kWfMaxPairs = 96u << 20;   // pairs the workspace of a batch-intersect slice is sized for: 48 B each + 4 B of queue
-constexpr uint64_t kWfRenderPairs = 384ull << 20;   // ... of a render slab (20 GB; the device has 288)
+constexpr uint64_t kWfRenderPairs = 768ull << 20;   // ... of a render slab (40 GB; the device has 288): slabs of 16 M paths on a 24-surface scene. Measured on the
+                                                    // atrium: 8 M-path slabs 300 Msamples/s, 16 M 325 — every step of a slab ends with a few waves finishing walks of hundreds of steps
 bool use_wavefront(const ptx_scene* sc) {
 	const size_t n_surf = sc->host.surfaces.size();
 	if (n_surf == 0 || n_surf > (size_t)kWfMaxSurfaces) return false;
@@ -510,20 +524,21 @@ bool use_wavefront(const ptx_scene* sc) {
 	if (const char* e = getenv("PTX_WAVEFRONT")) on = e[0] == '1';
 	return on;
 }
-hipError_t wf_workspace(ptx_ctx* c, size_t rays, size_t n_surf, WfBuffers& W) {
+hipError_t wf_workspace(ptx_ctx* c, int set, size_t rays, size_t n_surf, WfBuffers& W) {
+	ptx_ctx::WfSet& w = c->wf[set];
 	const size_t pairs = rays * n_surf;
 	hipError_t e;
-	if ((e = c->wf_pair_ray.ensure(pairs * 32)) != hipSuccess) return e;
-	if ((e = c->wf_pair_hit.ensure(pairs * 16)) != hipSuccess) return e;
-	if ((e = c->wf_queue.ensure(pairs * 4)) != hipSuccess) return e;
-	if ((e = c->wf_first.ensure(rays * 4)) != hipSuccess) return e;
-	if ((e = c->wf_mask.ensure(rays * 8)) != hipSuccess) return e;
-	if ((e = c->wf_ctr.ensure(kWfCtrBytes)) != hipSuccess) return e;
-	if ((e = c->wf_sched.ensure(wf_sched_bytes(n_surf))) != hipSuccess) return e;
-	if ((e = c->wf_spill.ensure((size_t)wf_traverse_grid(c->n_cu) * 4 * (size_t)kSpillWords * sizeof(uint2))) != hipSuccess) return e;
-	W.pair_ray = (float4*)c->wf_pair_ray.p; W.pair_hit = (float4*)c->wf_pair_hit.p; W.queue = (uint32_t*)c->wf_queue.p;
+	if ((e = w.pair_ray.ensure(pairs * 32)) != hipSuccess) return e;
+	if ((e = w.pair_hit.ensure(pairs * 16)) != hipSuccess) return e;
+	if ((e = w.queue.ensure(pairs * 4)) != hipSuccess) return e;
+	if ((e = w.first.ensure(rays * 4)) != hipSuccess) return e;
+	if ((e = w.mask.ensure(rays * 8)) != hipSuccess) return e;
+	if ((e = w.ctr.ensure(kWfCtrBytes)) != hipSuccess) return e;
+	if ((e = w.sched.ensure(wf_sched_bytes(n_surf))) != hipSuccess) return e;
+	if ((e = w.spill.ensure((size_t)wf_traverse_grid(c->n_cu) * 4 * (size_t)kSpillWords * sizeof(uint2))) != hipSuccess) return e;
+	W.pair_ray = (float4*)w.pair_ray.p; W.pair_hit = (float4*)w.pair_hit.p; W.queue = (uint32_t*)w.queue.p;
 	W.queue_cap = (uint32_t)rays;
-	W.first = (uint32_t*)c->wf_first.p; W.mask = (unsigned long long*)c->wf_mask.p; W.ctr = (uint32_t*)c->wf_ctr.p; W.sched = (uint32_t*)c->wf_sched.p; W.spill = (uint2*)c->wf_spill.p;
+	W.first = (uint32_t*)w.first.p; W.mask = (unsigned long long*)w.mask.p; W.ctr = (uint32_t*)w.ctr.p; W.sched = (uint32_t*)w.sched.p; W.spill = (uint2*)w.spill.p;
 	return hipSuccess;
 }
 
@@ -621,20 +636,30 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 		}
 	PassBuffers B{(float4*)c->queues.p, queue_stride, surface_units ? 1u : 0u, (float4*)c->sample_rad.p, (uint2*)c->spill.p, chunk_counter, ray_counter};
 	// queue-based pipeline (wavefront.hip): slab size from the pair budget — a step classifies two rays per path (extend + shadow)
-	WfBuffers WF{};
-	WfStream wf_st[2]{};
+	WfBuffers WF[2]{};
+	WfStream wf_st[2][2]{};
 	uint32_t wf_cap = 0;
+	int wf_sets = 1;
 	if (wavefront) {
 		const uint64_t pass_paths = (uint64_t)pass_spp * n_pixels;
-		wf_cap = (uint32_t)std::min<uint64_t>({pass_paths, (uint64_t)kWfMaxSlab, std::max<uint64_t>(65536, kWfRenderPairs / (2 * (uint64_t)n_surf))});
-		HIP_TRY(wf_workspace(c, 2 * (size_t)wf_cap, n_surf, WF));
-		WF.ray_counter = ray_counter;
-		HIP_TRY(c->wf_stream.ensure((size_t)wf_cap * 14 * sizeof(float4)));
-		HIP_TRY(c->wf_flow.ensure(64));
-		if (!c->wf_flow_host) HIP_TRY(hipHostMalloc((void**)&c->wf_flow_host, 64));
-		float4* base = (float4*)c->wf_stream.p;
-		wf_st[0] = WfStream{base, base + 8 * (size_t)wf_cap};
-		wf_st[1] = WfStream{base + 4 * (size_t)wf_cap, base + 11 * (size_t)wf_cap};
+		uint64_t pair_budget = kWfRenderPairs;
+		if (const char* e = getenv("PTX_WF_PAIRS_M")) pair_budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;   // measurement: workspace size in Mi pairs
+		wf_sets = getenv("PTX_WF_TWO_STREAMS") ? 2 : 1;   // measurement: two slabs side by side on two streams (neutral at 1080p, +45 % on 480x270 frames)
+		wf_cap = (uint32_t)std::min<uint64_t>({(pass_paths + wf_sets - 1) / wf_sets, (uint64_t)kWfMaxSlab - 1, std::max<uint64_t>(65536, pair_budget / (2 * (uint64_t)wf_sets * n_surf))});
+		if (!c->wf_main_ev) HIP_TRY(hipEventCreateWithFlags(&c->wf_main_ev, hipEventDisableTiming));
+		for (int k = 0; k < wf_sets; k++) {
+			ptx_ctx::WfSet& w = c->wf[k];
+			HIP_TRY(wf_workspace(c, k, 2 * (size_t)wf_cap, n_surf, WF[k]));
+			WF[k].ray_counter = ray_counter;
+			HIP_TRY(w.stream_buf.ensure((size_t)wf_cap * 14 * sizeof(float4)));
+			HIP_TRY(w.flow.ensure(64));
+			if (!w.flow_host) HIP_TRY(hipHostMalloc((void**)&w.flow_host, 64));
+			if (!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+			if (!w.done) HIP_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+			float4* base = (float4*)w.stream_buf.p;
+			wf_st[k][0] = WfStream{base, base + 8 * (size_t)wf_cap};
+			wf_st[k][1] = WfStream{base + 4 * (size_t)wf_cap, base + 11 * (size_t)wf_cap};
+		}
 	}
 	for (uint32_t p = 0; p < n_pass; p++) {
 		RenderParams P{};
@@ -651,17 +676,40 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 		HIP_TRY(hipMemsetAsync(chunk_counter, 0, 8, c->stream));
 		if (stats) HIP_TRY(hipEventRecord(c->events[2 * p], c->stream));
 		if (wavefront) {
-			// queue-based pipeline: the pass in slabs of at most `wf_cap` paths, each advanced step by step until no path is left
-			for (uint64_t first = 0; first < P.n_paths; first += wf_cap) {
-				uint32_t n_in = (uint32_t)std::min<uint64_t>(wf_cap, P.n_paths - first);
-				HIP_TRY(launch_wf_generate(sc->dev, P, wf_st[0], wf_cap, (uint32_t)first, n_in, B.sample_rad, c->stream));
-				if (P.bounces == 0) continue;
-				for (int cur = 0; n_in > 0; cur ^= 1) {
-					HIP_TRY(launch_wf_step(sc->dev, P, WF, wf_st[cur], wf_st[cur ^ 1], wf_cap, n_in, (uint32_t)first, (uint32_t*)c->wf_flow.p, B.sample_rad, c->n_cu, c->stream));
-					HIP_TRY(hipMemcpyAsync(c->wf_flow_host, c->wf_flow.p, 4, hipMemcpyDeviceToHost, c->stream));
-					HIP_TRY(hipStreamSynchronize(c->stream));
-					n_in = *c->wf_flow_host;
+			// queue-based pipeline: the pass in slabs of at most `wf_cap` paths, two at a time (one per workspace set and stream), each
+			// advanced step by step until no path is left
+			HIP_TRY(hipEventRecord(c->wf_main_ev, c->stream));
+			for (int k = 0; k < wf_sets; k++) HIP_TRY(hipStreamWaitEvent(c->wf[k].stream, c->wf_main_ev, 0));
+			for (uint64_t first = 0; first < P.n_paths; first += (uint64_t)wf_sets * wf_cap) {
+				uint32_t n_in[2] = {0, 0}, slab_first[2] = {0, 0};
+				int cur[2] = {0, 0};
+				for (int k = 0; k < wf_sets; k++) {
+					const uint64_t f = first + (uint64_t)k * wf_cap;
+					slab_first[k] = (uint32_t)f;
+					n_in[k] = f < P.n_paths ? (uint32_t)std::min<uint64_t>(wf_cap, P.n_paths - f) : 0u;
+					if (n_in[k]) HIP_TRY(launch_wf_generate(sc->dev, P, wf_st[k][0], wf_cap, slab_first[k], n_in[k], B.sample_rad, c->wf[k].stream));
 				}
+				if (P.bounces == 0) continue;
+				while (n_in[0] || n_in[1]) {
+					bool launched[2] = {false, false};
+					for (int k = 0; k < wf_sets; k++) {
+						if (!n_in[k]) continue;
+						ptx_ctx::WfSet& w = c->wf[k];
+						HIP_TRY(launch_wf_step(sc->dev, P, WF[k], wf_st[k][cur[k]], wf_st[k][cur[k] ^ 1], wf_cap, n_in[k], slab_first[k], (uint32_t*)w.flow.p, B.sample_rad, c->n_cu, w.stream));
+						HIP_TRY(hipMemcpyAsync(w.flow_host, w.flow.p, 4, hipMemcpyDeviceToHost, w.stream));
+						launched[k] = true;
+					}
+					for (int k = 0; k < wf_sets; k++) {
+						if (!launched[k]) continue;
+						HIP_TRY(hipStreamSynchronize(c->wf[k].stream));
+						n_in[k] = *c->wf[k].flow_host;
+						cur[k] ^= 1;
+					}
+				}
+			}
+			for (int k = 0; k < wf_sets; k++) {
+				HIP_TRY(hipEventRecord(c->wf[k].done, c->wf[k].stream));
+				HIP_TRY(hipStreamWaitEvent(c->stream, c->wf[k].done, 0));
 			}
 		} else
 			HIP_TRY(launch_render_pass(sc->dev, P, B, sc->mode, sc->lds_bytes, grid, c->stream));
@@ -738,7 +786,7 @@ int ptx_intersect_batch(ptx_scene* sc, const ptx_rays* r, size_t n, const ptx_hi
 		const size_t n_surf = sc->host.surfaces.size();
 		const size_t slice = std::min<size_t>(n, std::max<size_t>(65536, kWfMaxPairs / n_surf));
 		WfBuffers W{};
-		HIP_TRY(wf_workspace(c, slice, n_surf, W));
+		HIP_TRY(wf_workspace(c, 0, slice, n_surf, W));
 		for (size_t first = 0; first < n; first += slice) {
 			HIP_TRY(launch_wf_intersect(sc->dev, A, first, (uint32_t)std::min(slice, n - first), W, c->n_cu, c->stream));
 #ifdef PTX_WF_PROF
@@ -751,6 +799,7 @@ int ptx_intersect_batch(ptx_scene* sc, const ptx_rays* r, size_t n, const ptx_hi
 				fprintf(stderr, "WFPROF %-12s trips %10u lanes %11u  util %.3f  lanes/pair %.2f\n", names[k], ctr[160 + 2 * k], ctr[161 + 2 * k],
 				        ctr[160 + 2 * k] ? (double)ctr[161 + 2 * k] / (64.0 * ctr[160 + 2 * k]) : 0.0, (double)ctr[161 + 2 * k] / (double)ctr[0]);
 			static const char* tn[6] = {"kernel", "unit_fetch", "hand_out", "pop", "descend", "leaf"};
+			fprintf(stderr, "WFMAX slowest wave %u kcycles, most trips of a wave %u, longest walk of a lane %u steps\n", ctr[184], ctr[185], ctr[186]);
 			for (int k = 0; k < 6; k++) fprintf(stderr, "WFCLK %-10s %10u kcycles summed over waves (%.1f %%)\n", tn[k], ctr[176 + k], 100.0 * ctr[176 + k] / (double)ctr[176]);
 #endif
 		}

@@ -32,8 +32,13 @@ constexpr uint32_t kWfUnit = PTX_WF_UNIT;  // queue entries a wave takes per cou
 #ifndef PTX_WF_GRAB
 #define PTX_WF_GRAB 256
 #endif
-constexpr uint32_t kWfGrab = PTX_WF_GRAB;  // queue entries a wave reserves per atomic (a multiple of kWfUnit)
-constexpr int kWfLdsStack = PTX_WF_LDS_STACK;   // traversal-stack levels kept in LDS between the register levels and the global-memory overflow
+constexpr uint32_t kWfGrab = PTX_WF_GRAB;  // most queue entries a wave reserves per atomic (a multiple of kWfUnit)
+#ifndef PTX_WF_GUIDE_DIV
+#define PTX_WF_GUIDE_DIV 32
+#endif
+constexpr uint32_t kWfGuideDiv = PTX_WF_GUIDE_DIV;   // ... and the share of the stripe's remaining entries it reserves (about 1 / waves that work on a stripe)
+constexpr int kWfLdsStack = PTX_WF_LDS_STACK;
+   // traversal-stack levels kept in LDS between the register levels and the global-memory overflow
 #ifndef PTX_WF_REFILL_MIN
 #define PTX_WF_REFILL_MIN 8
 #endif
@@ -45,7 +50,7 @@ constexpr uint32_t kWfCtrLen = 64;
 // PTX_WF_PROF builds: wave-level trips and active lanes per region of k_wf_traverse, added into ctr[kWfCtrProf ..] (measurement only)
 [[maybe_unused]] constexpr uint32_t kWfCtrProf = 160;
 #ifdef PTX_WF_PROF
-#define WFPROF(k) do { const uint64_t m_ = __ballot(true); pl[k] += 1u; pt[k] += (lane == (uint32_t)(__ffsll((long long)m_) - 1)) ? 1u : 0u; } while (0)
+#define WFPROF(k) do { const uint64_t m_ = __ballot(true); pl[k] += 1u; pt[k] += (lane == (uint32_t)(__ffsll((long long)m_) - 1)) ? 1u : 0u; if ((k) == 2 || (k) == 3) walk_steps++; } while (0)
 // wave-level clock spent per region (kilocycles, lane 0 adds it up): T0 / T1 bracket a region executed under wave-uniform control flow
 #define WFT0() const uint64_t t0_ = __builtin_amdgcn_s_memtime()
 #define WFT1(k) do { tc[k] += __builtin_amdgcn_s_memtime() - t0_; } while (0)
@@ -233,6 +238,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 	uint32_t pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pl[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 outer rounds, 1 busy rounds, 2 node steps, 3 triangle tests, 4 hand-outs, 5 unit fetches, 6 pops
 	uint64_t tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // clocks: 0 whole kernel, 1 unit fetch, 2 hand-out, 3 pop, 4 descend loops, 5 leaf loops, 6 result stores
 	const uint64_t t_start = __builtin_amdgcn_s_memtime();
+	uint32_t walk_steps = 0, walk_max = 0;   // node steps + triangle tests of the lane's current walk / of its longest one
 #endif
 
 	for (;;) {
@@ -253,25 +259,34 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 						const uint32_t len = __builtin_amdgcn_readfirstlane(W.ctr[kWfCtrLen + u]);
 						const uint32_t slen = ((len + kWfStripes * kWfUnit - 1u) / (kWfStripes * kWfUnit)) * kWfUnit;   // entries per stripe
 						const uint32_t n_str = slen ? (len + slen - 1u) / slen : 0u;
+						if (len == 0) { order_pos++; continue; }
+						// what every stripe has handed out so far, in one instruction (lane c reads stripe c's counter): a wave that comes to an
+						// emptied queue learns it in one round trip instead of one failed reservation per stripe
 						uint32_t* sched = W.sched + (size_t)u * (kWfStripes + 1u) * kWfSchedStride;
-						const uint32_t done = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-						int st = -1;
-						for (uint32_t k = 0; k < n_str; k++) {
-							const uint32_t c = (stripe0 + k) % n_str;
-							if (!((done >> c) & 1u)) { st = (int)c; break; }
-						}
-						if (st < 0) { order_pos++; continue; }
-						const uint32_t lo = (uint32_t)st * slen, hi = lo + slen < len ? lo + slen : len;
+						uint32_t taken = 0xFFFFFFFFu;
+						if (lane < n_str) taken = __hip_atomic_load(sched + (size_t)(lane + 1u) * kWfSchedStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						const uint32_t my_len = lane < n_str ? ((lane + 1u) * slen < len ? slen : len - lane * slen) : 0u;
+						const uint64_t open_m = __ballot(lane < n_str && taken < my_len);
+						if (open_m == 0) { order_pos++; continue; }
+						// first open stripe at or after this wave's own one
+						const uint32_t s0 = stripe0 % n_str;
+						const uint64_t hi_m = open_m >> s0;
+						const uint32_t st_ = hi_m ? s0 + (uint32_t)__builtin_ctzll(hi_m) : (uint32_t)__builtin_ctzll(open_m);
+						const int st = (int)st_;
+						const uint32_t lo = st_ * slen, hi = lo + slen < len ? lo + slen : len;
+						// guided: a share of what the stripe still holds (whole units, at most kWfGrab entries), so that the waves of a launch run
+						// dry together — a unit is ~50 us of dependent fetches for one wave, whatever the rest of the chip is doing
+						const uint32_t remaining = hi - lo - __builtin_amdgcn_readlane(taken, st);
+						uint32_t want = remaining / kWfGuideDiv;
+						want = want > kWfGrab ? kWfGrab : want;
+						want = want < kWfUnit ? kWfUnit : want / kWfUnit * kWfUnit;
 						uint32_t b = 0;
-						if (lane == 0) b = atomicAdd(sched + (size_t)(st + 1) * kWfSchedStride, kWfGrab);
+						if (lane == 0) b = atomicAdd(sched + (size_t)(st + 1) * kWfSchedStride, want);
 						b = __builtin_amdgcn_readfirstlane(b);
-						if (lo + b >= hi) {
-							if (lane == 0) atomicOr(sched, 1u << st);
-							continue;
-						}
+						if (lo + b >= hi) continue;   // lost the race for the stripe's last entries: look again
 						unit_surf = u;
 						grab_pos = lo + b;
-						grab_end = grab_pos + kWfGrab < hi ? grab_pos + kWfGrab : hi;
+						grab_end = grab_pos + want < hi ? grab_pos + want : hi;
 						break;
 					}
 				}
@@ -300,6 +315,9 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 				const uint32_t r = rank_in(idle_m);
 				if (!busy && r < avail) {
 					WFPROF(4);
+#ifdef PTX_WF_PROF
+					walk_max = walk_steps > walk_max ? walk_steps : walk_max; walk_steps = 0;
+#endif
 					const uint32_t e = unit_pos - unit_base + r;
 					const float4 e0 = s_ray[wave][e][0], e1 = s_ray[wave][e][1];
 					pair = s_pair[wave][e];
@@ -357,22 +375,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 					const uint2 kid0 = g.nodes[nd.y >> 4], kid1 = g.nodes[(nd.y >> 4) + 1u];   // both children requested with the parent in hand
 					const float split = __uint_as_float(nd.x);
 					const float oa = sel3(o, axis), da = sel3(d, axis);
-#ifdef PTX_WF_ABL_DIV   // sensitivity measurement only: the step's division issued twice (the result is unchanged)
-					float da2 = da;
-					asm volatile("" : "+v"(da2));
-					const float sd2 = (split - oa) / da2;
-					const float sd1 = (split - oa) / da;
-					const float split_dist = sd2 < sd1 ? sd2 : sd1;
-#else
 					const float split_dist = (split - oa) / da;
-#endif
-#ifdef PTX_WF_ABL_LOAD  // sensitivity measurement only: the step's fetch issued twice (second copy: non-temporal flavour of the same address)
-					{
-						typedef uint32_t u4n __attribute__((ext_vector_type(4)));
-						const u4n x = __builtin_nontemporal_load(reinterpret_cast<const u4n*>(g.nodes + (nd.y >> 4)));
-						asm volatile("" :: "v"(x));
-					}
-#endif
 					const bool has_l = nd.y & 4u, has_r = nd.y & 8u;
 					const uint32_t li = nd.y >> 4, ri = li + (has_l ? 1u : 0u);
 					const bool left_first = oa < split;
@@ -430,6 +433,9 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 	}
 	tc[0] = __builtin_amdgcn_s_memtime() - t_start;
 	if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&W.ctr[kWfCtrProf + 16 + k], (uint32_t)(tc[k] >> 10));
+	// the slowest wave: its clock, its trips (node steps + triangle tests, wave level) and the most trips any single lane-walk took
+	if (lane == 0) { atomicMax(&W.ctr[kWfCtrProf + 24], (uint32_t)(tc[0] >> 10)); atomicMax(&W.ctr[kWfCtrProf + 25], pt[2] + pt[3]); }
+	atomicMax(&W.ctr[kWfCtrProf + 26], walk_steps > walk_max ? walk_steps : walk_max);
 #endif
 }
 

@@ -669,3 +669,89 @@ def test_hdr_environment_map_matches_oracle(ptx, ctx, ora):
         err = np.abs(got - ref).max(-1) / np.maximum(np.abs(ref).max(-1), 1e-3)
         assert (err < 1e-3).mean() > 0.99, f"srgb={srgb}: {(err < 1e-3).mean():.4%}"
     s.set_environment(None)
+
+
+# ---------------------------------------------------------------------------- queue-based pipeline (wavefront.hip) vs the fused kernel
+class _Pipeline:
+    """PTX_WAVEFRONT=0/1 for the calls inside (the library reads it per call): 0 = the fused kernel, 1 = the queue-based pipeline
+    wherever the scene keeps a global-memory copy of its trees."""
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        import os
+        self.old = os.environ.get("PTX_WAVEFRONT")
+        os.environ["PTX_WAVEFRONT"] = "1" if self.on else "0"
+
+    def __exit__(self, *a):
+        import os
+        if self.old is None:
+            os.environ.pop("PTX_WAVEFRONT", None)
+        else:
+            os.environ["PTX_WAVEFRONT"] = self.old
+
+
+def _both_pipelines(scene, **kw):
+    out = []
+    for on in (False, True):
+        with _Pipeline(on):
+            out.append(scene.render(**kw))
+    (a0, s0), (a1, s1) = out
+    np.testing.assert_array_equal(_bits(a1), _bits(a0))
+    assert s1["rays"] == s0["rays"] and s1["samples"] == s0["samples"]
+    return a1, s1
+
+
+@pytest.mark.parametrize("integrator", [0, 1])
+def test_queue_pipeline_frames_bitwise_equal_fused_kernel(ptx, ctx, integrator):
+    """The queue-based integrator (classify -> per-surface queues -> persistent traversal waves -> shade, stepped from the host) performs
+    the fused kernel's arithmetic on every ray, only elsewhere and later: accumulation buffers and ray counts must be bitwise equal —
+    on a many-surface model under the sun (its default case), on shadow-catcher / translucent / pass-through materials (pending and
+    zombie stream entries), on textures + alpha + sun, for tiles, sample offsets, pixel-list shards, odd sizes, 0 and 1 bounces."""
+    import os
+    from conftest import ROOT, product_from_dict
+    atr = product_from_dict(ptx, ctx, _proc().atrium_scene(2))
+    assert atr.info()["lds_resident"] != 1          # keeps a global-memory copy: the queue-based path is its default
+    for kw in (dict(W=160, H=90, spp=3, bounces=6), dict(W=97, H=61, spp=2, bounces=8, tile=(13, 7, 70, 41), sample0=5),
+               dict(W=128, H=128, spp=2, bounces=5, shard=(1, 3, 16)), dict(W=64, H=48, spp=2, bounces=0), dict(W=64, H=48, spp=3, bounces=1),
+               dict(W=160, H=90, spp=5, bounces=4, spp_per_pass=2)):
+        a, st = _both_pipelines(atr, integrator=integrator, **kw)
+        assert np.isfinite(a).all()
+    plaza = product_from_dict(ptx, ctx, _proc().plaza_scene(level=3, sun=True, alpha=True))   # shadow catcher + translucent sphere + sun
+    if plaza.info()["lds_resident"] != 1:
+        _both_pipelines(plaza, W=160, H=90, spp=4, bounces=6, integrator=integrator)
+    jack = ptx.Scene.load_gltf(ctx, os.path.join(ROOT, "scenes/jack-of-blades/jack-of-blades.gltf"))   # textures, normal maps, alpha, sun
+    _both_pipelines(jack, W=120, H=68, spp=2, bounces=5, integrator=integrator)
+
+
+def test_queue_pipeline_intersections_bitwise_equal_fused_kernel(ptx, ctx):
+    """ptx_intersect_batch through the queues (many-surface scenes by default) against the fused kernel: every output word equal, for
+    camera rays, bounce rays off the hit points, rays that miss everything, axis-parallel and non-finite rays, and a batch that is
+    processed in several slices (PTX_WAVEFRONT forces the path per call)."""
+    from conftest import product_from_dict
+    s = product_from_dict(ptx, ctx, _proc().atrium_scene(3))
+    cam = s.array(ptx.ARR_CAMERA)
+    rng = np.random.default_rng(3)
+    n = 150_000
+    org = np.tile(cam[:3].astype(np.float32), (n, 1))
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    with _Pipeline(False):
+        h0 = s.intersect(org, d)
+    hit = h0["surface"] >= 0
+    assert 0.3 < hit.mean() < 1.0
+    p = np.stack([h0["px"], h0["py"], h0["pz"]], 1)[hit]
+    nn = np.stack([h0["nx"], h0["ny"], h0["nz"]], 1)[hit]
+    d2 = rng.standard_normal(p.shape).astype(np.float32)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True).astype(np.float32)
+    d2 = np.where((d2 * nn).sum(1, keepdims=True) < 0, -d2, d2).astype(np.float32)
+    special_o = np.array([[0, 1, 0], [0, 1, 0], [0, 1, 0], [100, 100, 100], [0, 1, 0], [np.nan, 0, 0]], np.float32)
+    special_d = np.array([[1, 0, 0], [0, -1, 0], [0, 0, 1], [0, 1, 0], [np.inf, 0, 0], [0, 1, 0]], np.float32)
+    o_all = np.concatenate([org, p + nn * np.float32(1e-4), special_o]).astype(np.float32)
+    d_all = np.concatenate([d, d2, special_d]).astype(np.float32)
+    with _Pipeline(False):
+        ref = s.intersect(o_all, d_all)
+    with _Pipeline(True):
+        got = s.intersect(o_all, d_all)
+    for k in ref:
+        np.testing.assert_array_equal(np.asarray(got[k]).view(np.uint32), np.asarray(ref[k]).view(np.uint32), err_msg=k)

@@ -37,9 +37,9 @@ int main() {
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
 	printf("%10s %6s %6s %14s %14s\n", "bytes", "waves", "lanes", "Gloads/s", "ns/step/wave");
 	const int steps = 2000;
-	for (int logn : {16, 18, 21, 23, 26}) {            // 1 MiB, 4 MiB, 32 MiB, 128 MiB, 1 GiB
+	for (int logn : {9, 10, 12, 16, 18, 21, 23, 26}) {   // 8 KiB, 16 KiB, 64 KiB (vector L1 is 32 KiB), 1 MiB, 4 MiB, 32 MiB, 128 MiB, 1 GiB
 		for (int wps : {1, 2, 4, 6, 8}) {                // waves per SIMD = 256-thread blocks per CU
-			for (uint32_t lanes : {4u, 16u, 64u}) {
+			for (uint32_t lanes : {4u, 16u, 32u, 64u}) {
 				const uint32_t mask = ((uint32_t)1 << logn) - 1u;
 				const int grid = n_cu * wps;
 				hipLaunchKernelGGL(k_chase, dim3(grid), dim3(256), 0, 0, d, mask, 200, lanes, out);
