@@ -33,7 +33,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 CORNELL = os.path.join(ROOT, "scenes", "cornell-box", "cornell.gltf")
-KERNEL_SRC = os.path.join(ROOT, "distributed-path-tracer_amd", "csrc", "kernels.hip")
+KERNEL_SRCS = [os.path.join(ROOT, "distributed-path-tracer_amd", "csrc", f) for f in ("kernels.hip", "device_core.hpp")]   # what k_render_pass is compiled from
 
 W, H, SPP, BOUNCES = 1920, 1080, 256, 8
 # /opt/skills/guides/MI355X_MICROARCH.md
@@ -44,6 +44,14 @@ MAX_CLOCK_GHZ = 2.4            # "Max clock 2400 MHz" (chip-level parameters)
 # triangle records (8*3.44 + 40*11.82 = 500 B per ray on the Cornell trees) are served by LDS in this kernel and never reach HBM
 B_STREAM, B_ATTR = 188.0, 192.0
 B_RAY_CORNELL_ALL = 188 + 8 * 3.44 + 40 * 11.82 + 192   # the full §8(d) figure (880.3), reported for reference
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in KERNEL_SRCS:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def kernel_profile():
@@ -57,8 +65,7 @@ def kernel_profile():
     with open(files[-1]) as fh:
         p = json.load(fh)
     p["file"] = os.path.relpath(files[-1], ROOT)
-    with open(KERNEL_SRC, "rb") as fh:
-        p["stale"] = hashlib.sha256(fh.read()).hexdigest()[:16] != p.get("kernels_hip_sha256_16")
+    p["stale"] = kernel_source_hash() != p.get("kernels_hip_sha256_16")
     return p
 
 

@@ -610,8 +610,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 	bool surface_units = max_per_model >= 8 && n_surf <= (uint32_t)kMaxDeferModels;   // measured: +49 % on a 24-surface model, -2..-7 % on scenes of 1-3 surfaces per model
 	if (const char* e = getenv("PTX_SURFACE_UNITS")) surface_units = e[0] == '1' && n_surf <= (uint32_t)kMaxDeferModels;
 	const uint32_t queue_stride = queue_float4_per_wave(surface_units ? n_surf : n_mod);
-	const bool wavefront = use_wavefront(sc);
-	if (!wavefront) HIP_TRY(c->queues.ensure(n_slots * (size_t)queue_stride * sizeof(float4)));
+	bool wavefront = use_wavefront(sc);
 	HIP_TRY(c->sample_rad.ensure((size_t)pass_spp * n_pixels * sizeof(float4)));
 	HIP_TRY(c->counters.ensure(1024));   // [0] chunk counter, [16] ray counter, [64..] PTX_PROF region counters
 	HIP_TRY(c->spill.ensure(n_slots * (size_t)kSpillWords * sizeof(uint2)));
@@ -645,22 +644,38 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 		uint64_t pair_budget = kWfRenderPairs;
 		if (const char* e = getenv("PTX_WF_PAIRS_M")) pair_budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;   // measurement: workspace size in Mi pairs
 		wf_sets = getenv("PTX_WF_TWO_STREAMS") ? 2 : 1;   // measurement: two slabs side by side on two streams (neutral at 1080p, +45 % on 480x270 frames)
-		wf_cap = (uint32_t)std::min<uint64_t>({(pass_paths + wf_sets - 1) / wf_sets, (uint64_t)kWfMaxSlab - 1, std::max<uint64_t>(65536, pair_budget / (2 * (uint64_t)wf_sets * n_surf))});
 		if (!c->wf_main_ev) HIP_TRY(hipEventCreateWithFlags(&c->wf_main_ev, hipEventDisableTiming));
-		for (int k = 0; k < wf_sets; k++) {
-			ptx_ctx::WfSet& w = c->wf[k];
-			HIP_TRY(wf_workspace(c, k, 2 * (size_t)wf_cap, n_surf, WF[k]));
-			WF[k].ray_counter = ray_counter;
-			HIP_TRY(w.stream_buf.ensure((size_t)wf_cap * 14 * sizeof(float4)));
-			HIP_TRY(w.flow.ensure(64));
-			if (!w.flow_host) HIP_TRY(hipHostMalloc((void**)&w.flow_host, 64));
-			if (!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
-			if (!w.done) HIP_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
-			float4* base = (float4*)w.stream_buf.p;
-			wf_st[k][0] = WfStream{base, base + 8 * (size_t)wf_cap};
-			wf_st[k][1] = WfStream{base + 4 * (size_t)wf_cap, base + 11 * (size_t)wf_cap};
+		auto allocate = [&]() -> hipError_t {
+			hipError_t e;
+			for (int k = 0; k < wf_sets; k++) {
+				ptx_ctx::WfSet& w = c->wf[k];
+				if ((e = wf_workspace(c, k, 2 * (size_t)wf_cap, n_surf, WF[k])) != hipSuccess) return e;
+				WF[k].ray_counter = ray_counter;
+				if ((e = w.stream_buf.ensure((size_t)wf_cap * 14 * sizeof(float4))) != hipSuccess) return e;
+				if ((e = w.flow.ensure(64)) != hipSuccess) return e;
+				if (!w.flow_host && (e = hipHostMalloc((void**)&w.flow_host, 64)) != hipSuccess) return e;
+				if (!w.stream && (e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking)) != hipSuccess) return e;
+				if (!w.done && (e = hipEventCreateWithFlags(&w.done, hipEventDisableTiming)) != hipSuccess) return e;
+				float4* base = (float4*)w.stream_buf.p;
+				wf_st[k][0] = WfStream{base, base + 8 * (size_t)wf_cap};
+				wf_st[k][1] = WfStream{base + 4 * (size_t)wf_cap, base + 11 * (size_t)wf_cap};
+			}
+			return hipSuccess;
+		};
+		// the pair space is sized for the worst case; when the device cannot spare that much, smaller slabs, and below 32 Mi pairs the fused kernel
+		for (;;) {
+			wf_cap = (uint32_t)std::min<uint64_t>({(pass_paths + wf_sets - 1) / wf_sets, (uint64_t)kWfMaxSlab - 1, std::max<uint64_t>(65536, pair_budget / (2 * (uint64_t)wf_sets * n_surf))});
+			const hipError_t e = allocate();
+			if (e == hipSuccess) break;
+			if (e != hipErrorOutOfMemory) return set_err(PTX_ERR_HIP, std::string("queue-based pipeline workspace: ") + hipGetErrorString(e));
+			(void)hipGetLastError();
+			for (auto& w : c->wf)
+				for (DevBuf* b : {&w.pair_ray, &w.pair_hit, &w.queue, &w.first, &w.mask, &w.stream_buf}) b->release();
+			pair_budget /= 2;
+			if (pair_budget < (32ull << 20)) { wavefront = false; break; }
 		}
 	}
+	if (!wavefront) HIP_TRY(c->queues.ensure(n_slots * (size_t)queue_stride * sizeof(float4)));
 	for (uint32_t p = 0; p < n_pass; p++) {
 		RenderParams P{};
 		P.W = cfg->W; P.H = cfg->H; P.x0 = x0; P.y0 = y0; P.w = w; P.h = h;

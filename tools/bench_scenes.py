@@ -23,7 +23,7 @@ want = lambda k: not only or k in only
 
 
 def run(name, scene, spp):
-    scene.render(W, H, 2, B, accum=accum, want_stats=True, integrator=args.integrator)          # warm-up
+    scene.render(W, H, spp, B, accum=accum, want_stats=True, integrator=args.integrator)        # warm-up: same size, so that every workspace has its final size
     accum.zero_(); torch.cuda.synchronize()
     t = time.perf_counter()
     _, st = scene.render(W, H, spp, B, accum=accum, want_stats=True, integrator=args.integrator)
