@@ -633,7 +633,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 			HIP_TRY(hipEventCreate(&ev));
 			c->events.push_back(ev);
 		}
-	PassBuffers B{(float4*)c->queues.p, queue_stride, surface_units ? 1u : 0u, (float4*)c->sample_rad.p, (uint2*)c->spill.p, chunk_counter, ray_counter};
+	PassBuffers B{nullptr /* the fused kernel's streams: set below, once it is known which pipeline runs */, queue_stride, surface_units ? 1u : 0u, (float4*)c->sample_rad.p, (uint2*)c->spill.p, chunk_counter, ray_counter};
 	// queue-based pipeline (wavefront.hip): slab size from the pair budget — a step classifies two rays per path (extend + shadow)
 	WfBuffers WF[2]{};
 	WfStream wf_st[2][2]{};
@@ -675,7 +675,10 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 			if (pair_budget < (32ull << 20)) { wavefront = false; break; }
 		}
 	}
-	if (!wavefront) HIP_TRY(c->queues.ensure(n_slots * (size_t)queue_stride * sizeof(float4)));
+	if (!wavefront) {
+		HIP_TRY(c->queues.ensure(n_slots * (size_t)queue_stride * sizeof(float4)));
+		B.queues = (float4*)c->queues.p;
+	}
 	for (uint32_t p = 0; p < n_pass; p++) {
 		RenderParams P{};
 		P.W = cfg->W; P.H = cfg->H; P.x0 = x0; P.y0 = y0; P.w = w; P.h = h;
@@ -726,8 +729,10 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 				HIP_TRY(hipEventRecord(c->wf[k].done, c->wf[k].stream));
 				HIP_TRY(hipStreamWaitEvent(c->stream, c->wf[k].done, 0));
 			}
-		} else
+		} else {
+			if (!B.queues || !B.sample_rad || !B.spill) return set_err(PTX_ERR_HIP, "ptx_render: workspace of the fused kernel is not allocated");
 			HIP_TRY(launch_render_pass(sc->dev, P, B, sc->mode, sc->lds_bytes, grid, c->stream));
+		}
 		if (stats) HIP_TRY(hipEventRecord(c->events[2 * p + 1], c->stream));
 		HIP_TRY(launch_resolve(B.sample_rad, d_accum, d_pixels, P.n_pixels, P.pass_spp, c->stream));
 	}
