@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 
 #include "flat_scene.hpp"
 
@@ -130,7 +131,12 @@ constexpr size_t kWfCtrBytes = 192 * 4;   // [0] pairs, [64 + u] queue lengths, 
 constexpr uint32_t kWfStripes = 16, kWfSchedStride = 64;
 inline size_t wf_sched_bytes(size_t n_surf) { return n_surf * (kWfStripes + 1u) * kWfSchedStride * 4; }
 constexpr int kWfMaxSurfaces = 64;   // surface masks are one 64-bit word
-inline int wf_traverse_grid(int n_cu) { return n_cu * 8; }   // persistent 256-thread workgroups: as many as can be resident (8 waves per SIMD at most)
+// persistent 256-thread workgroups of the traverse kernel: as many as can be resident (8 per CU at most; registers and LDS allow 5-6).
+// PTX_WF_GRID=<workgroups per CU> (measurement): fewer leave room for another stream's kernels
+inline int wf_traverse_grid(int n_cu) {
+	static const int per_cu = [] { const char* e = getenv("PTX_WF_GRID"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }();
+	return n_cu * per_cu;
+}
 hipError_t launch_wf_generate(const DevScene& S, const RenderParams& P, const WfStream& out, uint32_t cap, uint32_t first, uint32_t n, float4* sample_rad, hipStream_t stream);
 hipError_t launch_wf_step(const DevScene& S, const RenderParams& P, const WfBuffers& W, const WfStream& in, const WfStream& out, uint32_t cap, uint32_t n_in,
                           uint32_t slab_first, uint32_t* n_out, float4* sample_rad, int n_cu, hipStream_t stream);

@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 				while ((nd.y & 3u) != KD_LEAF) {
 					WFPROF(2);
 					const uint32_t axis = nd.y & 3u;
-					const uint2 kid0 = g.nodes[nd.y >> 4], kid1 = g.nodes[(nd.y >> 4) + 1u];   // both children requested with the parent in hand
+					const uint2 kid0 = g.nodes[nd.y >> 4], kid1 = g.nodes[(nd.y >> 4) + 1u];   // both children requested with the parent in hand (fetching only the chosen one afterwards: -5 %)
 					const float split = __uint_as_float(nd.x);
 					const float oa = sel3(o, axis), da = sel3(d, axis);
 					const float split_dist = (split - oa) / da;
