@@ -17,6 +17,9 @@
 #include <cstring>
 #include <deque>
 #include <limits>
+#include <atomic>
+#include <memory>
+#include <thread>
 #include <tuple>
 
 namespace ptx {
@@ -73,7 +76,9 @@ struct MeshBuilder {
 	std::vector<BuildNode> nodes;
 	uint32_t max_depth_seen = 0;
 
-	int32_t build(const Box& box, std::vector<uint32_t>&& ids, int levels_left, uint32_t depth) {
+	// par_levels > 0: the left subtree of a large node is built by a second thread into a builder of its own and grafted in afterwards
+	// (child links are indices into `nodes`; the emitted tree does not depend on where a node sits in that vector)
+	int32_t build(const Box& box, std::vector<uint32_t>&& ids, int levels_left, uint32_t depth, int par_levels = 0) {
 		int32_t me = (int32_t)nodes.size();
 		nodes.emplace_back();
 		max_depth_seen = std::max(max_depth_seen, depth);
@@ -139,8 +144,25 @@ struct MeshBuilder {
 			if (any_r) rids.push_back(t);
 		}
 		std::vector<uint32_t>().swap(ids);
-		if (!lids.empty()) { int32_t c = build(l, std::move(lids), levels_left - 1, depth + 1); nodes[me].left = c; }
-		if (!rids.empty()) { int32_t c = build(r, std::move(rids), levels_left - 1, depth + 1); nodes[me].right = c; }
+		if (par_levels > 0 && !lids.empty() && !rids.empty() && lids.size() + rids.size() >= 16384) {
+			MeshBuilder sub{pa, pb, pc, {}, 0};
+			std::thread th([&] { sub.build(l, std::move(lids), levels_left - 1, depth + 1, par_levels - 1); });
+			const int32_t c = build(r, std::move(rids), levels_left - 1, depth + 1, par_levels - 1);
+			nodes[me].right = c;
+			th.join();
+			const int32_t off = (int32_t)nodes.size();
+			nodes.reserve(nodes.size() + sub.nodes.size());
+			for (BuildNode& bn : sub.nodes) {
+				if (bn.left >= 0) bn.left += off;
+				if (bn.right >= 0) bn.right += off;
+				nodes.push_back(std::move(bn));
+			}
+			nodes[me].left = off;
+			max_depth_seen = std::max(max_depth_seen, sub.max_depth_seen);
+			return me;
+		}
+		if (!lids.empty()) { int32_t c = build(l, std::move(lids), levels_left - 1, depth + 1, par_levels); nodes[me].left = c; }
+		if (!rids.empty()) { int32_t c = build(r, std::move(rids), levels_left - 1, depth + 1, par_levels); nodes[me].right = c; }
 		return me;
 	}
 };
@@ -166,6 +188,11 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 		s.vattr[i] = {v[5], v[6], v[7], v[3], v[8], v[9], v[10], v[4]};
 	}
 
+	// Per surface: records (in surface order), then the SAH builds — the expensive part, independent of each other: in parallel, one
+	// surface per thread, and the top levels of a surface's own recursion on further threads when there are fewer surfaces than cores
+	// (PTX_BUILD_THREADS overrides the thread count; the emitted arrays do not depend on it) — then the emission, in surface order again.
+	struct SurfaceBuild { std::vector<F3> pa, pb, pc; Box box; std::unique_ptr<MeshBuilder> tree; };
+	std::vector<SurfaceBuild> sb(n_surf);
 	for (size_t si = 0; si < n_surf; si++) {
 		int32_t* rg = &s.surf_range[8 * si];
 		const int32_t v0 = rg[0], nvs = rg[1], t0 = rg[2], nt = rg[3];
@@ -178,7 +205,9 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 		memcpy(sr.bmax, mb.hi, 12);
 		sr.tri_base = (uint32_t)t0;
 
-		std::vector<F3> pa(nt), pb(nt), pc(nt);
+		std::vector<F3>& pa = sb[si].pa; std::vector<F3>& pb = sb[si].pb; std::vector<F3>& pc = sb[si].pc;
+		pa.resize(nt); pb.resize(nt); pc.resize(nt);
+		sb[si].box = mb;
 		for (int32_t t = 0; t < nt; t++) {
 			const uint32_t* ix = &s.triangles[3 * (size_t)(t0 + t)];
 			const float* a = &s.vertices[11 * (size_t)(v0 + ix[0])];
@@ -205,10 +234,33 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 			const float pad = 4 * kEps * max_edge + kEps;
 			for (int k = 0; k < 3; k++) { sr.pbmin[k] = sr.bmin[k] - pad; sr.pbmax[k] = sr.bmax[k] + pad; }
 		}
-		MeshBuilder mbuild{pa, pb, pc, {}, 0};
-		std::vector<uint32_t> all(nt);
-		for (int32_t t = 0; t < nt; t++) all[t] = (uint32_t)t;
-		mbuild.build(mb, std::move(all), 25, 1);  // mesh.hpp:34: max_depth = 25
+	}
+	{
+		unsigned n_threads = std::thread::hardware_concurrency();
+		if (const char* e = getenv("PTX_BUILD_THREADS")) n_threads = (unsigned)std::max(1, atoi(e));
+		n_threads = std::max(1u, std::min(n_threads, 32u));
+		int par_levels = 0;   // 2^par_levels subtree tasks per surface when surfaces alone do not fill the threads
+		while (n_surf && (n_surf << par_levels) < n_threads && par_levels < 5) par_levels++;
+		std::atomic<size_t> next_surface{0};
+		auto worker = [&] {
+			for (size_t si = next_surface++; si < n_surf; si = next_surface++) {
+				const int32_t nt = s.surf_range[8 * si + 3];
+				sb[si].tree.reset(new MeshBuilder{sb[si].pa, sb[si].pb, sb[si].pc, {}, 0});
+				std::vector<uint32_t> all(nt);
+				for (int32_t t = 0; t < nt; t++) all[t] = (uint32_t)t;
+				sb[si].tree->build(sb[si].box, std::move(all), 25, 1, par_levels);  // mesh.hpp:34: max_depth = 25
+			}
+		};
+		std::vector<std::thread> pool;
+		for (unsigned k = 1; k < std::min<size_t>(n_threads, n_surf); k++) pool.emplace_back(worker);
+		worker();
+		for (std::thread& t : pool) t.join();
+	}
+	for (size_t si = 0; si < n_surf; si++) {
+		int32_t* rg = &s.surf_range[8 * si];
+		const int32_t t0 = rg[2];
+		SurfaceRec& sr = s.surfaces[si];
+		MeshBuilder& mbuild = *sb[si].tree;
 		s.kd_max_depth = std::max(s.kd_max_depth, mbuild.max_depth_seen);
 
 		// Emission order. Children of a branch are always adjacent (the node stores the index of the first one).
@@ -251,6 +303,7 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 		sr.kd_root = node0;
 		rg[4] = (int32_t)node0; rg[5] = (int32_t)(s.kd_nodes.size() - node0);
 		rg[6] = (int32_t)ref0;  rg[7] = (int32_t)(s.kd_refs.size() - ref0);
+		sb[si] = SurfaceBuild{};   // the build tree of this surface is no longer needed
 
 		const float* m = &s.materials_raw[11 * si];
 		MaterialRec& mr = s.materials[si];
