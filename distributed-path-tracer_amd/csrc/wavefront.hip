@@ -20,25 +20,25 @@
 
 namespace ptx {
 
-constexpr int kWfBlock = 256;              // threads per workgroup of the traverse / merge kernels
+// Tunables (the -D overrides are for tools/build_variant.sh A/B builds; measured values in profiles/round2_wf_ab.txt)
+constexpr int kWfBlock = 256;              // threads per workgroup of the traverse / shade / merge kernels
 constexpr int kWfClassifyBlock = 1024;     // ... of the classify kernel: queue space is reserved per workgroup
 #ifndef PTX_WF_UNIT
 #define PTX_WF_UNIT 64
 #endif
-constexpr uint32_t kWfUnit = PTX_WF_UNIT;  // queue entries a wave takes per counter fetch and stages into its LDS slice
-#ifndef PTX_WF_LDS_STACK
-#define PTX_WF_LDS_STACK 8
-#endif
+constexpr uint32_t kWfUnit = PTX_WF_UNIT;  // queue entries a wave stages into its LDS slice at a time
 #ifndef PTX_WF_GRAB
 #define PTX_WF_GRAB 256
 #endif
-constexpr uint32_t kWfGrab = PTX_WF_GRAB;  // most queue entries a wave reserves per atomic (a multiple of kWfUnit)
+constexpr uint32_t kWfGrab = PTX_WF_GRAB;  // most queue entries a wave reserves per atomic (a multiple of kWfUnit) ...
 #ifndef PTX_WF_GUIDE_DIV
 #define PTX_WF_GUIDE_DIV 32
 #endif
 constexpr uint32_t kWfGuideDiv = PTX_WF_GUIDE_DIV;   // ... and the share of the stripe's remaining entries it reserves (about 1 / waves that work on a stripe)
-constexpr int kWfLdsStack = PTX_WF_LDS_STACK;
-   // traversal-stack levels kept in LDS between the register levels and the global-memory overflow
+#ifndef PTX_WF_LDS_STACK
+#define PTX_WF_LDS_STACK 8
+#endif
+constexpr int kWfLdsStack = PTX_WF_LDS_STACK;         // traversal-stack levels kept in LDS between the register levels and the global-memory overflow
 #ifndef PTX_WF_REFILL_MIN
 #define PTX_WF_REFILL_MIN 8
 #endif
