@@ -263,3 +263,24 @@ def test_pass_through_cap_is_a_documented_safety_bound(ptx, ctx):
     a, st = s.render(4, 3, 2, 3)
     assert np.isfinite(a).all() and (a[..., :3] == 0).all() and (a[..., 3] == 2).all()
     assert st["rays"] == 4 * 3 * 2 * 4097
+
+
+def test_pass_throughs_on_the_queue_based_pipeline(ptx, ctx, monkeypatch):
+    """The same two pass-through cases through wavefront.hip (a scene made to keep its trees in global memory, PTX_FORCE_GLOBAL at
+    creation; PTX_WAVEFRONT per call): one stream entry per pass-through and step — 40 half-transparent layers bitwise equal to the
+    fused kernel; 4200 fully transparent ones stop at the same bound after exactly 4097 closest-hit queries per sample, 4097 steps."""
+    monkeypatch.setenv("PTX_FORCE_GLOBAL", "1")
+    s40, s4200 = _from(ptx, ctx, _glass_stack(40, 0.5)), _from(ptx, ctx, _glass_stack(4200, 0.0))
+    monkeypatch.delenv("PTX_FORCE_GLOBAL")
+    assert s40.info()["lds_resident"] == 0
+    out = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("PTX_WAVEFRONT", on)
+        out.append(s40.render(24, 16, 6, 2))
+    (a0, st0), (a1, st1) = out
+    np.testing.assert_array_equal(a1.view(np.uint32), a0.view(np.uint32))
+    assert st1["rays"] == st0["rays"] > 2.5 * 24 * 16 * 6
+    monkeypatch.setenv("PTX_WAVEFRONT", "1")
+    a, st = s4200.render(4, 3, 2, 3)
+    assert np.isfinite(a).all() and (a[..., :3] == 0).all() and (a[..., 3] == 2).all()
+    assert st["rays"] == 4 * 3 * 2 * 4097
