@@ -819,6 +819,9 @@ int ptx_intersect_batch(ptx_scene* sc, const ptx_rays* r, size_t n, const ptx_hi
 				fprintf(stderr, "WFPROF %-12s trips %10u lanes %11u  util %.3f  lanes/pair %.2f\n", names[k], ctr[160 + 2 * k], ctr[161 + 2 * k],
 				        ctr[160 + 2 * k] ? (double)ctr[161 + 2 * k] / (64.0 * ctr[160 + 2 * k]) : 0.0, (double)ctr[161 + 2 * k] / (double)ctr[0]);
 			static const char* tn[6] = {"kernel", "unit_fetch", "hand_out", "pop", "descend", "leaf"};
+			fprintf(stderr, "WFHIST waves by log2(kilocycles of their run):");
+			for (int k = 0; k < 31; k++) if (ctr[128 + k]) fprintf(stderr, " [2^%d]=%u", k, ctr[128 + k]);
+			fprintf(stderr, "  waves that never had a busy round: %u\n", ctr[128 + 31]);
 			fprintf(stderr, "WFMAX slowest wave %u kcycles, most trips of a wave %u, longest walk of a lane %u steps\n", ctr[184], ctr[185], ctr[186]);
 			for (int k = 0; k < 6; k++) fprintf(stderr, "WFCLK %-10s %10u kcycles summed over waves (%.1f %%)\n", tn[k], ctr[176 + k], 100.0 * ctr[176 + k] / (double)ctr[176]);
 #endif

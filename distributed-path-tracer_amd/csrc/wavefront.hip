@@ -436,6 +436,8 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 	// the slowest wave: its clock, its trips (node steps + triangle tests, wave level) and the most trips any single lane-walk took
 	if (lane == 0) { atomicMax(&W.ctr[kWfCtrProf + 24], (uint32_t)(tc[0] >> 10)); atomicMax(&W.ctr[kWfCtrProf + 25], pt[2] + pt[3]); }
 	atomicMax(&W.ctr[kWfCtrProf + 26], walk_steps > walk_max ? walk_steps : walk_max);
+	// when the waves ended, in eighths of ... the clock of the wave itself, binned by log2 of kilocycles (ctr[128 .. 159]: free in these builds)
+	if (lane == 0) { const uint32_t kc = (uint32_t)(tc[0] >> 10); atomicAdd(&W.ctr[128 + (kc ? 31 - __builtin_clz(kc) : 0)], 1u); if (pt[1] == 0) atomicAdd(&W.ctr[128 + 31], 1u); }
 #endif
 }
 
