@@ -115,7 +115,7 @@ struct WfBuffers {
 	uint32_t* first;               // [rays] first pair of the ray
 	unsigned long long* mask;      // [rays] bit u: the ray enters surface u
 	uint32_t* ctr;                 // counters block, zeroed per launch (wavefront.hip: kWfCtr*)
-	uint32_t* sched;               // [n_surfaces][1 + kWfStripes][kWfSchedStride]: per queue one hand-out counter per stripe (slot 1 ..), 256 bytes apart; zeroed per launch
+	uint32_t* sched;               // [n_surfaces][1 + kWfStripes][kWfSchedStride]: per queue the count of its closed stripes (slot 0) and one hand-out counter per stripe (slots 1 ..), 256 bytes apart, then the 64-bit mask of closed queues; zeroed per launch
 	uint2* spill;                  // [wf_traverse_grid * 4 waves][kSpillWords]
 	unsigned long long* ray_counter;   // nullptr, or where classify adds the number of rays it was given (render statistics)
 };
@@ -129,7 +129,7 @@ constexpr uint32_t kWfIdMask = 0x00FFFFFFu, kWfZombie = 1u << 31, kWfPending = 1
 constexpr uint32_t kWfMaxSlab = 1u << 24;
 constexpr size_t kWfCtrBytes = 192 * 4;   // [0] pairs, [64 + u] queue lengths, [128 + u] hand-out positions, [160 ..] PTX_WF_PROF region counters
 constexpr uint32_t kWfStripes = 16, kWfSchedStride = 64;
-inline size_t wf_sched_bytes(size_t n_surf) { return n_surf * (kWfStripes + 1u) * kWfSchedStride * 4; }
+inline size_t wf_sched_bytes(size_t n_surf) { return (n_surf * (kWfStripes + 1u) + 1u) * kWfSchedStride * 4; }   // + the mask word of closed queues
 constexpr int kWfMaxSurfaces = 64;   // surface masks are one 64-bit word
 // persistent 256-thread workgroups of the traverse kernel: as many as can be resident (8 per CU at most; registers and LDS allow 5-6).
 // PTX_WF_GRID=<workgroups per CU> (measurement): fewer leave room for another stream's kernels

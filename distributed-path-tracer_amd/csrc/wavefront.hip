@@ -225,7 +225,8 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 	uint32_t unit_pos = 0, unit_end = 0, unit_base = 0, order_pos = 0, grab_pos = 0, grab_end = 0;
 	const uint32_t stripe0 = (blockIdx.x / 8u) * (kWfBlock / 64) + wave;   // where this wave starts in a queue: the waves of an XCD spread over the stripes
 	int unit_surf = -1;
-	bool more = true;
+	bool more = true, stripe_open = false, queue_done = false;
+	uint32_t stripe_cur = 0, stripe_lo = 0, stripe_hi = 0, stripe_rem = 0, stripe_n = 0;   // the stripe this wave is reserving from
 	// per lane: the walk in progress (core::mesh::intersect's locals, as in mesh_traverse)
 	bool busy = false, have = false;
 	uint32_t pair = 0, node = 0;
@@ -248,46 +249,69 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 			if (unit_pos == unit_end) {
 				WFT0();
 				// next unit: the rest of this wave's grab, else a new grab — this XCD's queues first. A queue is handed out in kWfStripes
-				// contiguous stripes, each with its own counter in its own 256 bytes: one counter per queue, two dozen of them in one
-				// cache line, made every hand-out of the chip queue up in one L2 channel (measured: units of 32 / 64 / 128 entries ran at
-				// 656 / 1000 / 1306 Mrays/s). An exhausted stripe is marked in the queue's `done` word and passed over with a plain load.
+				// contiguous stripes, each with its own counter in its own 256 bytes (one counter per queue, two dozen of them in one cache
+				// line, made every hand-out of the chip queue up in one L2 channel: units of 32 / 64 / 128 entries ran at 656 / 1000 /
+				// 1306 Mrays/s). Reads of these words serialise in L2 like the atomics do, so a wave reads as little as it can: a grab is
+				// ONE atomic on the wave's current stripe (what it returns says how much the stripe still holds); the wave whose grab takes
+				// a stripe's last entry counts the stripe closed, the one that closes a queue's last stripe sets the queue's bit in one
+				// mask word — a wave looking for work reads that word, then the 16 counters of one open queue, and a wave that finds the
+				// mask full is done after one read (with every wave polling every stripe counter, a launch of FOUR pairs took 1 ms).
 				if (grab_pos == grab_end) {
+					unsigned long long* const closed_mask = reinterpret_cast<unsigned long long*>(W.sched + (size_t)n_surf * (kWfStripes + 1u) * kWfSchedStride);
 					for (;;) {
-						if (order_pos >= n_order) { more = false; break; }
-						const int u = wf_surface_at(xcd, order_pos, n_surf);
-						if (u < 0) { order_pos++; continue; }
-						const uint32_t len = __builtin_amdgcn_readfirstlane(W.ctr[kWfCtrLen + u]);
+						if (stripe_open) {
+							uint32_t want = stripe_rem / kWfGuideDiv;   // guided: a share of what the stripe still holds, whole units, at most kWfGrab entries
+							want = want > kWfGrab ? kWfGrab : want;
+							want = want < kWfUnit ? kWfUnit : want / kWfUnit * kWfUnit;
+							uint32_t* sched = W.sched + (size_t)unit_surf * (kWfStripes + 1u) * kWfSchedStride;
+							uint32_t b = 0;
+							if (lane == 0) b = atomicAdd(sched + (size_t)(stripe_cur + 1u) * kWfSchedStride, want);
+							b = __builtin_amdgcn_readfirstlane(b);
+							if (stripe_lo + b < stripe_hi) {
+								grab_pos = stripe_lo + b;
+								grab_end = grab_pos + want < stripe_hi ? grab_pos + want : stripe_hi;
+								stripe_rem = stripe_hi - grab_end;
+								if (grab_end == stripe_hi) {   // this grab holds the stripe's last entry: exactly one wave gets here per stripe
+									stripe_open = false;
+									if (lane == 0) {
+										const uint32_t closed = atomicAdd(sched, 1u) + 1u;
+										if (closed == stripe_n) atomicOr(closed_mask, 1ull << unit_surf);
+									}
+								}
+								break;
+							}
+							stripe_open = false;   // others took the rest meanwhile
+						}
+						// another stripe of the current queue, else the next open queue in this XCD's order
+						if (unit_surf < 0 || queue_done) {
+							if (order_pos >= n_order) { more = false; break; }
+							const unsigned long long closed = __hip_atomic_load(closed_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							int u = -1;
+							for (; order_pos < n_order; order_pos++) {
+								const int c = wf_surface_at(xcd, order_pos, n_surf);
+								if (c >= 0 && !((closed >> c) & 1ull) && W.ctr[kWfCtrLen + c] != 0) { u = c; break; }
+							}
+							u = __builtin_amdgcn_readfirstlane(u);
+							if (u < 0) { more = false; break; }
+							unit_surf = u;
+							queue_done = false;
+						}
+						const uint32_t len = __builtin_amdgcn_readfirstlane(W.ctr[kWfCtrLen + unit_surf]);
 						const uint32_t slen = ((len + kWfStripes * kWfUnit - 1u) / (kWfStripes * kWfUnit)) * kWfUnit;   // entries per stripe
-						const uint32_t n_str = slen ? (len + slen - 1u) / slen : 0u;
-						if (len == 0) { order_pos++; continue; }
-						// what every stripe has handed out so far, in one instruction (lane c reads stripe c's counter): a wave that comes to an
-						// emptied queue learns it in one round trip instead of one failed reservation per stripe
-						uint32_t* sched = W.sched + (size_t)u * (kWfStripes + 1u) * kWfSchedStride;
-						uint32_t taken = 0xFFFFFFFFu;
-						if (lane < n_str) taken = __hip_atomic_load(sched + (size_t)(lane + 1u) * kWfSchedStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						const uint32_t my_len = lane < n_str ? ((lane + 1u) * slen < len ? slen : len - lane * slen) : 0u;
-						const uint64_t open_m = __ballot(lane < n_str && taken < my_len);
-						if (open_m == 0) { order_pos++; continue; }
-						// first open stripe at or after this wave's own one
-						const uint32_t s0 = stripe0 % n_str;
+						stripe_n = (len + slen - 1u) / slen;
+						uint32_t* sched = W.sched + (size_t)unit_surf * (kWfStripes + 1u) * kWfSchedStride;
+						uint32_t taken = 0xFFFFFFFFu;   // lane c: what stripe c has handed out so far
+						if (lane < stripe_n) taken = __hip_atomic_load(sched + (size_t)(lane + 1u) * kWfSchedStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						const uint32_t my_len = lane < stripe_n ? ((lane + 1u) * slen < len ? slen : len - lane * slen) : 0u;
+						const uint64_t open_m = __ballot(lane < stripe_n && taken < my_len);
+						if (open_m == 0) { queue_done = true; order_pos++; continue; }
+						const uint32_t s0 = stripe0 % stripe_n;   // first open stripe at or after this wave's own one
 						const uint64_t hi_m = open_m >> s0;
-						const uint32_t st_ = hi_m ? s0 + (uint32_t)__builtin_ctzll(hi_m) : (uint32_t)__builtin_ctzll(open_m);
-						const int st = (int)st_;
-						const uint32_t lo = st_ * slen, hi = lo + slen < len ? lo + slen : len;
-						// guided: a share of what the stripe still holds (whole units, at most kWfGrab entries), so that the waves of a launch run
-						// dry together — a unit is ~50 us of dependent fetches for one wave, whatever the rest of the chip is doing
-						const uint32_t remaining = hi - lo - __builtin_amdgcn_readlane(taken, st);
-						uint32_t want = remaining / kWfGuideDiv;
-						want = want > kWfGrab ? kWfGrab : want;
-						want = want < kWfUnit ? kWfUnit : want / kWfUnit * kWfUnit;
-						uint32_t b = 0;
-						if (lane == 0) b = atomicAdd(sched + (size_t)(st + 1) * kWfSchedStride, want);
-						b = __builtin_amdgcn_readfirstlane(b);
-						if (lo + b >= hi) continue;   // lost the race for the stripe's last entries: look again
-						unit_surf = u;
-						grab_pos = lo + b;
-						grab_end = grab_pos + want < hi ? grab_pos + want : hi;
-						break;
+						stripe_cur = hi_m ? s0 + (uint32_t)__builtin_ctzll(hi_m) : (uint32_t)__builtin_ctzll(open_m);
+						stripe_lo = stripe_cur * slen;
+						stripe_hi = stripe_lo + slen < len ? stripe_lo + slen : len;
+						stripe_rem = stripe_hi - stripe_lo - __builtin_amdgcn_readlane(taken, stripe_cur);
+						stripe_open = true;
 					}
 				}
 				if (more) {
