@@ -717,6 +717,18 @@ def test_queue_pipeline_frames_bitwise_equal_fused_kernel(ptx, ctx, integrator):
                dict(W=160, H=90, spp=5, bounces=4, spp_per_pass=2)):
         a, st = _both_pipelines(atr, integrator=integrator, **kw)
         assert np.isfinite(a).all()
+    # many small slabs per pass (a pair budget of 1 Mi pairs: 65 536-path slabs), and two slabs side by side on two streams
+    import os
+    for var, val in (("PTX_WF_PAIRS_M", "1"), ("PTX_WF_TWO_STREAMS", "1")):
+        os.environ[var] = val
+        try:
+            _both_pipelines(atr, W=480, H=270, spp=3, bounces=5, integrator=integrator)
+            if var == "PTX_WF_PAIRS_M":
+                os.environ["PTX_WF_TWO_STREAMS"] = "1"
+                _both_pipelines(atr, W=480, H=270, spp=2, bounces=4, integrator=integrator, tile=(100, 50, 300, 200))
+                os.environ.pop("PTX_WF_TWO_STREAMS")
+        finally:
+            os.environ.pop(var, None)
     plaza = product_from_dict(ptx, ctx, _proc().plaza_scene(level=3, sun=True, alpha=True))   # shadow catcher + translucent sphere + sun
     if plaza.info()["lds_resident"] != 1:
         _both_pipelines(plaza, W=160, H=90, spp=4, bounces=6, integrator=integrator)
