@@ -76,6 +76,12 @@ class RenderStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("passes", C.c_uint64), ("kernel_ms", C.c_double)]
 
 
+class KernelTiming(C.Structure):
+    _fields_ = [("pipeline", C.c_uint32), ("steps", C.c_uint32), ("classify_ms", C.c_double), ("traverse_ms", C.c_double), ("shade_ms", C.c_double),
+                ("fused_ms", C.c_double), ("fused_launches", C.c_uint32), ("reserved", C.c_uint32), ("pool_pairs", C.c_uint64),
+                ("peak_pairs", C.c_uint64), ("slab_paths", C.c_uint64), ("workspace_bytes", C.c_uint64)]
+
+
 class Rays(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ox", "oy", "oz", "dx", "dy", "dz")]
 
@@ -140,6 +146,8 @@ def lib():
         L.ptx_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.ptx_ctx_destroy.argtypes = [C.c_void_p]
         L.ptx_ctx_synchronize.argtypes = [C.c_void_p]
+        L.ptx_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.ptx_ctx_get_timing.argtypes = [C.c_void_p, C.POINTER(KernelTiming)]
         L.ptx_scene_load_gltf.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(LoadOpts), C.POINTER(C.c_void_p)]
         L.ptx_worker_event_load.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(RenderCfg), C.POINTER(WorkerEvent)]
         L.ptx_scene_from_arrays.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
@@ -152,6 +160,7 @@ def lib():
         L.ptx_intersect_batch.argtypes = [C.c_void_p, C.POINTER(Rays), C.c_size_t, C.POINTER(Hits)]
         L.ptx_tonemap_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.ptx_pbr_eval_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.ptx_camera_rays_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.ptx_reduce_framebuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.ptx_encode_png.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.ptx_free.argtypes = [C.c_void_p]
@@ -192,6 +201,16 @@ class Context:
 
     def synchronize(self):
         _check(lib().ptx_ctx_synchronize(self.h))
+
+    def set_timing(self, on=True):
+        """ptx_ctx_set_timing: collect per-kernel HIP-event times of the queue-based pipeline in renders that ask for stats."""
+        _check(lib().ptx_ctx_set_timing(self.h, int(bool(on))))
+
+    def timing(self):
+        """ptx_ctx_get_timing: where the time of the last render with stats went, and the workspace it used."""
+        t = KernelTiming()
+        _check(lib().ptx_ctx_get_timing(self.h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in KernelTiming._fields_ if n != "reserved"}
 
     def reduce_framebuffer(self, nccl_comm, accum, root=0):
         """ptx_reduce_framebuffer: in-place RCCL sum-reduce of a device-resident accumulation buffer onto `root`, on this
@@ -332,6 +351,13 @@ class Scene:
         """renderer::environment = image_texture::load(png_path, srgb): the miss colour becomes map(direction) * environment_factor.
         None removes the map."""
         _check(lib().ptx_scene_set_environment(self.h, os.fsencode(png_path) if png_path is not None else None, int(bool(srgb))))
+
+    def camera_rays(self, ndc_ratio):
+        """ptx_camera_rays_batch: [n,3] float32 (ndc.x, ndc.y, aspect ratio) -> [n,6] float32 (origin, direction) = scene::camera::get_ray."""
+        a = np.ascontiguousarray(ndc_ratio, np.float32).reshape(-1, 3)
+        out = np.zeros((len(a), 6), np.float32)
+        _check(lib().ptx_camera_rays_batch(self.h, a.ctypes.data, len(a), out.ctypes.data))
+        return out
 
     def intersect(self, origins, dirs, attributes=True):
         """Batch closest-hit. origins/dirs: [n,3] float32 numpy. Returns dict of numpy arrays."""

@@ -541,14 +541,8 @@ DEV float4 draws(const RenderParams& P, uint32_t pixel, uint32_t sample, uint32_
 	return make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
 }
 
-// scene::camera::get_ray — scene/camera.cpp:10-21 ; pixel loop of renderer::render — core/renderer.cpp:359-370
-DEV void camera_ray(const DevScene& S, const RenderParams& P, uint32_t x, uint32_t y, uint32_t sample, V3& o, V3& d) {
-	float4 j = draws(P, y * P.W + x, sample, 0, 0, BLOCK_JITTER);
-	if (P.integrator == 1u && sample == 0) j.x = j.y = 0;   // HOST worker.cpp:125-126: the first sample is not offset
-	float ndc_x = (((float)x + j.x) / (float)P.W) * 2 - 1;
-	float ndc_y = (((float)y + j.y) / (float)P.H) * 2 - 1;
-	ndc_y = -ndc_y;
-	float ratio = (float)P.W / (float)P.H;
+// scene::camera::get_ray(ndc, ratio) — scene/camera.cpp:10-21
+DEV void camera_get_ray(const DevScene& S, float ndc_x, float ndc_y, float ratio, V3& o, V3& d) {
 	float dx = S.cam.tan_half_fov * ndc_x, dy = S.cam.tan_half_fov * ndc_y;
 	dx *= ratio;
 	V3 dir = normalize(mk(dx, dy, -1));
@@ -556,6 +550,16 @@ DEV void camera_ray(const DevScene& S, const RenderParams& P, uint32_t x, uint32
 	V3 z = {0, 0, 0};
 	o = mulmv(S.cam.basis, z) + mk(S.cam.origin[0], S.cam.origin[1], S.cam.origin[2]);
 	d = normalize(mulmv(S.cam.basis, dir));
+}
+// pixel loop of renderer::render — core/renderer.cpp:359-370: jitter -> NDC -> camera ray
+DEV void camera_ray(const DevScene& S, const RenderParams& P, uint32_t x, uint32_t y, uint32_t sample, V3& o, V3& d) {
+	float4 j = draws(P, y * P.W + x, sample, 0, 0, BLOCK_JITTER);
+	if (P.integrator == 1u && sample == 0) j.x = j.y = 0;   // HOST worker.cpp:125-126: the first sample is not offset
+	float ndc_x = (((float)x + j.x) / (float)P.W) * 2 - 1;
+	float ndc_y = (((float)y + j.y) / (float)P.H) * 2 - 1;
+	ndc_y = -ndc_y;
+	float ratio = (float)P.W / (float)P.H;
+	camera_get_ray(S, ndc_x, ndc_y, ratio, o, d);
 }
 
 // ------------------------------------------------------------------------------------ textures

@@ -79,7 +79,8 @@ struct Decoder {
 	int app14_transform = -1, rgb_ids = 0;
 	Component comp[4];
 	Huff hdc[4], hac[4];
-	uint16_t dequant[4][64];
+	uint16_t dequant[4][64] = {};
+	bool dq_present[4] = {false, false, false, false};
 	int h_max = 1, v_max = 1, mcu_w = 0, mcu_h = 0, mcu_x = 0, mcu_y = 0;
 	int restart_interval = 0, todo = 0;
 	// scan state
@@ -111,6 +112,7 @@ struct Decoder {
 	int bits(int n) {   // n in 0..16
 		if (n == 0) return 0;
 		if (code_bits < n) grow();
+		if (code_bits < n) return 0;   // the entropy data ended at a marker: stb_image v2.30 reads zeros from there on, and so does this reader
 		const uint32_t k = code_buffer >> (32 - n);
 		code_buffer <<= n;
 		code_bits -= n;
@@ -120,6 +122,8 @@ struct Decoder {
 	// receive n bits and sign-extend the JPEG way (a leading 0 bit means negative: value - (2^n - 1))
 	int extend_receive(int n) {
 		if (n == 0) return 0;
+		if (code_bits < n) grow();
+		if (code_bits < n) return 0;   // out of bits: the value 0, not the sign extension of n zero bits
 		const int v = bits(n);
 		return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v;
 	}
@@ -128,7 +132,7 @@ struct Decoder {
 		const uint32_t top = code_buffer >> 16;
 		int len = 1;
 		while (top >= h.maxcode[len]) len++;
-		if (len > 16) bad(path, "bad Huffman code");
+		if (len > 16 || len > code_bits) bad(path, "bad Huffman code");   // a code that needs bits the stream no longer has
 		const int idx = (int)(code_buffer >> (32 - len)) + h.delta[len];
 		if (idx < 0 || idx >= 256) bad(path, "bad Huffman code");
 		code_buffer <<= len;
@@ -142,6 +146,18 @@ struct Decoder {
 		eob_run = 0;
 	}
 
+	// A corrupt stream can run the DC predictor out of int range, or its dequantised value out of the 16-bit coefficient: refused
+	// (as stb_image v2.30 refuses them: "bad delta", "can't merge dc and ac") instead of overflowing a signed integer
+	int checked_dc(int pred, int diff, int factor) {
+		const long long dc = (long long)pred + diff;
+		if (dc > 0x7FFFFFFFll || dc < -0x80000000ll) bad(path, "corrupt JPEG: DC predictor out of range");
+		const long long v = dc * factor;
+		if (v > 32767 || v < -32768) bad(path, "corrupt JPEG: DC coefficient out of range");
+		return (int)dc;
+	}
+	void need_quant(const Component& c) {
+		if (!dq_present[c.tq]) bad(path, "component uses a quantisation table that was not defined");
+	}
 	// ---------------- baseline block: Huffman -> dequantised coefficients in natural order
 	void decode_block(int16_t data[64], Component& c) {
 		const Huff& dc = hdc[c.hd];
@@ -151,7 +167,7 @@ struct Decoder {
 		const int t = decode(dc);
 		if (t > 15) bad(path, "bad DC size");
 		const int diff = t ? extend_receive(t) : 0;
-		c.dc_pred += diff;
+		c.dc_pred = checked_dc(c.dc_pred, diff, (int)dq[0]);
 		data[0] = (int16_t)(c.dc_pred * dq[0]);
 		for (int k = 1; k < 64;) {
 			const int rs = decode(ac), s = rs & 15, r = rs >> 4;
@@ -173,7 +189,7 @@ struct Decoder {
 			const int t = decode(hdc[c.hd]);
 			if (t > 15) bad(path, "bad DC size");
 			const int diff = t ? extend_receive(t) : 0;
-			c.dc_pred += diff;
+			c.dc_pred = checked_dc(c.dc_pred, diff, 1 << succ_low);
 			data[0] = (int16_t)(c.dc_pred * (1 << succ_low));
 		} else if (bit()) {
 			data[0] = (int16_t)(data[0] + (1 << succ_low));
@@ -307,6 +323,7 @@ struct Decoder {
 			const int q = get8(), prec = q >> 4, t = q & 15;
 			if ((prec != 0 && prec != 1) || t > 3) bad(path, "bad DQT");
 			for (int i = 0; i < 64; i++) dequant[t][kZigzag[i]] = (uint16_t)(prec ? get16() : get8());
+			dq_present[t] = true;
 			len -= prec ? 129 : 65;
 		}
 		if (len != 0) bad(path, "bad DQT length");
@@ -410,7 +427,7 @@ struct Decoder {
 		reset_entropy();
 		int16_t blk[64];
 		if (!progressive) {
-			for (int i = 0; i < scan_n; i++) need_tables(comp[order[i]], true, true);
+			for (int i = 0; i < scan_n; i++) { need_tables(comp[order[i]], true, true); need_quant(comp[order[i]]); }
 			if (scan_n == 1) {   // non-interleaved: the component's own blocks, row by row, only those that cover the image
 				Component& c = comp[order[0]];
 				const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
@@ -468,6 +485,7 @@ struct Decoder {
 		for (int n = 0; n < n_comp; n++) {
 			Component& c = comp[n];
 			const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
+			need_quant(c);
 			const uint16_t* dq = dequant[c.tq];
 			for (int j = 0; j < h; j++)
 				for (int i = 0; i < w; i++) {

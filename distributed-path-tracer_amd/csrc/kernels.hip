@@ -529,6 +529,17 @@ __global__ void k_pbr_eval(const float* __restrict__ in, float* __restrict__ out
 	q[12] = rf.x; q[13] = rf.y; q[14] = rf.z;
 }
 
+// ------------------------------------------------------------------------------------ batch camera rays
+// scene::camera::get_ray(ndc, ratio) exactly as the integrator kernels inline it, one record per lane (ptx_camera_rays_batch)
+__global__ void k_camera_rays(DevScene S, const float* __restrict__ in, float* __restrict__ out, size_t n) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	V3 o, d;
+	camera_get_ray(S, in[3 * i], in[3 * i + 1], in[3 * i + 2], o, d);
+	float* q = out + 6 * i;
+	q[0] = o.x; q[1] = o.y; q[2] = o.z; q[3] = d.x; q[4] = d.y; q[5] = d.z;
+}
+
 // ------------------------------------------------------------------------------------ tonemap + encode
 // core::tonemap_approx_aces (core/utils.hpp:29-36) + image::image::write (image/image.cpp:143-154)
 DEV float aces1(float x) {
@@ -624,6 +635,10 @@ hipError_t launch_intersect(const DevScene& S, const IntersectArgs& A, int mode,
 }
 hipError_t launch_pbr_eval(const float* in, float* out, size_t n, hipStream_t stream) {
 	hipLaunchKernelGGL(k_pbr_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, out, n);
+	return hipGetLastError();
+}
+hipError_t launch_camera_rays(const DevScene& S, const float* in, float* out, size_t n, hipStream_t stream) {
+	hipLaunchKernelGGL(k_camera_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, in, out, n);
 	return hipGetLastError();
 }
 hipError_t launch_tonemap(const float4* accum, uint32_t n_pixels, float spp, const float* thresholds, uchar4* out, hipStream_t stream) {

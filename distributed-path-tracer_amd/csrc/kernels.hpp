@@ -105,41 +105,51 @@ struct IntersectArgs {
 	uint2* spill;                                // [grid * waves per block][kSpillWords]
 };
 
-// Workspace of the queue-based pipeline (wavefront.hip). A PAIR is (ray, surface whose box it enters); the pairs of a ray are
-// consecutive, in surface order. Sized for the worst case (every ray enters every surface): what is touched is what is used.
+// Workspace of the queue-based pipeline (wavefront.hip). A PAIR is (ray, surface whose box it enters). Pair space is a POOL sized from
+// demand (a ray enters 3-5 of an atrium's 24 surface boxes, not all of them): every classify tile (1024 rays) reserves its pairs with
+// ONE atomic and uses its block of the pool twice — as queue entries grouped by surface (what the traversal waves read, contiguous
+// per surface: one SEGMENT per tile and surface) and as result slots grouped by ray (what the shading / merge kernels read: the
+// pairs of a ray are consecutive, in surface order). A step whose pairs do not fit the pool raises the overflow word; the host then
+// repeats the slab in smaller pieces.
 struct WfBuffers {
-	float4* pair_ray;              // [pairs][2]: (local origin, surface id bits) (local direction, -)
-	float4* pair_hit;              // [pairs]: (local t, global triangle id bits, beta, gamma); t = -1: the walk found nothing
-	uint32_t* queue;               // [n_surfaces][queue_cap] pair indices, one queue per surface
-	uint32_t queue_cap;            // rays of the launch
-	uint32_t* first;               // [rays] first pair of the ray
+	float4* qent;                  // [pool_cap][2] queue entries: (local origin, result slot bits) (local direction, -)
+	float4* pair_hit;              // [pool_cap] results: (local t, global triangle id bits, beta, gamma); t = -1: the walk found nothing
+	uint32_t pool_cap;             // pairs the pool holds
+	uint2* seg;                    // [n_surfaces][seg_cap]: (first entry, entries) of the segments of each surface's queue
+	uint32_t seg_cap;              // classify tiles of a step at most
+	uint32_t* first;               // [rays] first result slot of the ray
 	unsigned long long* mask;      // [rays] bit u: the ray enters surface u
-	uint32_t* ctr;                 // counters block, zeroed per launch (wavefront.hip: kWfCtr*)
-	uint32_t* sched;               // [n_surfaces][1 + kWfStripes][kWfSchedStride]: per queue the count of its closed stripes (slot 0) and one hand-out counter per stripe (slots 1 ..), 256 bytes apart, then the 64-bit mask of closed queues; zeroed per launch
+	uint32_t* ctl;                 // control block of THIS step (kWfCtlWords words, zeroed before the step; layout below)
+	const uint32_t* n_in;          // device word: stream entries of this step (render) / rays of this slice (batch intersect)
+	uint32_t* overflow;            // device word, sticky over the steps of a slab: some step's pairs did not fit the pool
+	uint32_t* peak;                // device word: the most pairs any step of the slab asked for (what the host sizes the next slab by)
 	uint2* spill;                  // [wf_traverse_grid * 4 waves][kSpillWords]
 	unsigned long long* ray_counter;   // nullptr, or where classify adds the number of rays it was given (render statistics)
 };
+// control block of a step (uint32 words): [0] pairs reserved so far, [1] this step overflowed the pool, [kWfCtlSeg + u] segments of
+// surface u's queue, [kWfCtlCur + 64 u] hand-out cursor of surface u's segments (256 bytes apart: two dozen hot counters in one
+// cache line serialised every hand-out of the chip in one L2 channel), [kWfCtlProf ..] PTX_WF_PROF region counters
+constexpr uint32_t kWfCtlSeg = 16, kWfCtlProf = 80, kWfCtlCur = 192, kWfCtlWords = kWfCtlCur + 64u * 64u;
+constexpr uint32_t kWfTile = 1024;   // rays per classify tile = threads of a classify workgroup
 // One of the two path-stream buffers of a render slab (SoA of float4, `cap` entries per array)
 struct WfStream {
 	float4* q;   // [4][cap]: (origin, id | flags) (direction, T.x) (T.y, T.z, L.x, L.y) (L.z, depth << 16 | pass, RNG key pixel, RNG key sample) — the fused kernel's entry
 	float4* r;   // [3][cap]: the entry's shadow request: (origin, -) (direction, -) (x: radiance to add when unoccluded | origin of a shadow catcher's pass-through ray, -)
 };
-// flags in the id word of a stream entry (ids are slab-local, < 2^24)
-constexpr uint32_t kWfIdMask = 0x00FFFFFFu, kWfZombie = 1u << 31, kWfPending = 1u << 30, kWfRequest = 1u << 29;
-constexpr uint32_t kWfMaxSlab = 1u << 24;
-constexpr size_t kWfCtrBytes = 192 * 4;   // [0] pairs, [64 + u] queue lengths, [128 + u] hand-out positions, [160 ..] PTX_WF_PROF region counters
-constexpr uint32_t kWfStripes = 16, kWfSchedStride = 64;
-inline size_t wf_sched_bytes(size_t n_surf) { return (n_surf * (kWfStripes + 1u) + 1u) * kWfSchedStride * 4; }   // + the mask word of closed queues
+// flags in the id word of a stream entry (ids are slab-local, < 2^28)
+constexpr uint32_t kWfIdMask = 0x0FFFFFFFu, kWfZombie = 1u << 31, kWfPending = 1u << 30, kWfRequest = 1u << 29;
+constexpr uint32_t kWfMaxSlab = 1u << 26;   // paths of a slab at most (the stream buffers of a slab take 224 bytes per path)
 constexpr int kWfMaxSurfaces = 64;   // surface masks are one 64-bit word
-// persistent 256-thread workgroups of the traverse kernel: as many as can be resident (8 per CU at most; registers and LDS allow 5-6).
+// persistent 256-thread workgroups of the traverse kernel: as many as can be resident (registers allow 5 per CU, LDS 6).
 // PTX_WF_GRID=<workgroups per CU> (measurement): fewer leave room for another stream's kernels
 inline int wf_traverse_grid(int n_cu) {
 	static const int per_cu = [] { const char* e = getenv("PTX_WF_GRID"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }();
 	return n_cu * per_cu;
 }
+// a slab's steps run back to back on the device: step s reads its entry count from flow[s] and adds what it emits to flow[s + 1]
 hipError_t launch_wf_generate(const DevScene& S, const RenderParams& P, const WfStream& out, uint32_t cap, uint32_t first, uint32_t n, float4* sample_rad, hipStream_t stream);
-hipError_t launch_wf_step(const DevScene& S, const RenderParams& P, const WfBuffers& W, const WfStream& in, const WfStream& out, uint32_t cap, uint32_t n_in,
-                          uint32_t slab_first, uint32_t* n_out, float4* sample_rad, int n_cu, hipStream_t stream);
+hipError_t launch_wf_step(const DevScene& S, const RenderParams& P, const WfBuffers& W, const WfStream& in, const WfStream& out, uint32_t cap, uint32_t max_in,
+                          uint32_t slab_first, uint32_t* n_out, float4* sample_rad, int n_cu, hipStream_t stream, hipEvent_t* ev /* nullptr, or 4 events: before classify / traverse / shade, after */);
 hipError_t launch_wf_intersect(const DevScene& S, const IntersectArgs& A, size_t first_ray, uint32_t n, const WfBuffers& W, int n_cu, hipStream_t stream);
 
 hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const PassBuffers& B, int mode, size_t lds_bytes, int grid,
@@ -147,6 +157,7 @@ hipError_t launch_render_pass(const DevScene& S, const RenderParams& P, const Pa
 hipError_t launch_resolve(const float4* sample_rad, float4* accum, const uint32_t* pixels, uint32_t n_pixels, uint32_t pass_spp, hipStream_t stream);
 hipError_t launch_intersect(const DevScene& S, const IntersectArgs& A, int mode, size_t lds_bytes, int grid, hipStream_t stream);
 hipError_t launch_pbr_eval(const float* in, float* out, size_t n, hipStream_t stream);
+hipError_t launch_camera_rays(const DevScene& S, const float* in /* [n][3]: ndc.x ndc.y ratio */, float* out /* [n][6] */, size_t n, hipStream_t stream);
 hipError_t launch_tonemap(const float4* accum, uint32_t n_pixels, float spp, const float* thresholds /* [256], device */, uchar4* out, hipStream_t stream);
 
 }  // namespace ptx

@@ -72,6 +72,9 @@ void read_png(const std::string& path, uint32_t& W, uint32_t& H, uint32_t& C, st
 	}
 	size_t raw_size = 0;
 	for (const Pass& ps : passes) raw_size += (row_bytes(ps.w) + 1) * ps.h;
+	// a header cannot demand more memory than the file could possibly fill: deflate expands at most 1032 : 1 (IHDR allows 65536 x 65536
+	// at 64 bits per pixel — 32 GiB zero-filled before inflate would fail), and the readers cap an image at 2^28 pixels
+	if ((uint64_t)W * H > ((uint64_t)1 << 28) || raw_size > idat.size() * 1032 + 64) bad(path, "image data too short for the declared size");
 	std::vector<uint8_t> raw(raw_size);
 	uLongf raw_len = (uLongf)raw.size();
 	if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) bad(path, "inflate failed");

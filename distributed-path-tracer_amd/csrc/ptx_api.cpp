@@ -86,13 +86,17 @@ struct ptx_ctx {
 	// its own set: the end of one slab's traverse kernel (a few waves finishing walks of hundreds of dependent fetches) and the host's
 	// wait for its entry count then run under the other slab's kernels. ptx_intersect_batch uses set 0 on the context's stream.
 	struct WfSet {
-		DevBuf pair_ray, pair_hit, queue, first, mask, ctr, sched, spill, stream_buf, flow;
-		uint32_t* flow_host = nullptr;   // pinned: entries the last step wrote
+		DevBuf qent, pair_hit, seg, first, mask, ctl, spill, stream_buf, flow;
+		uint32_t* flow_host = nullptr;   // pinned copy of the flow words (kWfFlowWords)
 		hipStream_t stream = nullptr;
 		hipEvent_t done = nullptr;
 	} wf[2];
 	hipEvent_t wf_main_ev = nullptr;
 	std::vector<hipEvent_t> events;
+	// per-kernel timing of the last ptx_render that was given a stats pointer (ptx_ctx_set_timing / ptx_ctx_get_timing)
+	bool timing_on = false;
+	std::vector<hipEvent_t> step_events;
+	ptx_kernel_timing timing{};
 	// pixel list of the last sharded render (ptx_render_cfg::shard_*), kept on the device: a frame is usually rendered again
 	// with the same sharding (sample ranges, benchmark steps)
 	uint32_t list_key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -105,6 +109,7 @@ struct ptx_scene {
 	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr, d_isect, d_shade, d_tex, d_texels, d_lut, d_spaces, d_model_space;
 	DevBuf d_res_nodes, d_res_refs, d_res_tris, d_texels_f;
 	DevScene dev{};
+	double wf_pairs_per_ray = 0;   // queue-based pipeline: pairs (ray, entered surface) per ray seen so far on this scene, 0 = not yet measured
 	bool leaf_ordered = true; // global-memory copy of the triangle records: per leaf reference (true) or per triangle (false)
 	int mode = MODE_GLOBAL;   // where the traversal arrays live: MODE_GLOBAL / MODE_LDS / MODE_HYBRID (kernels.hip)
 	size_t lds_bytes = 0;     // dynamic LDS of the kernels (resident arrays + shade records)
@@ -272,9 +277,10 @@ static void ctx_release(ptx_ctx* c) {
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
 	for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
+	for (hipEvent_t ev : c->step_events) (void)hipEventDestroy(ev);
 	c->queues.release(); c->spill.release(); c->sample_rad.release(); c->counters.release(); c->stage_a.release(); c->stage_b.release(); c->pixel_list.release(); c->srgb_thr.release();
 	for (auto& w : c->wf) {
-		for (DevBuf* b : {&w.pair_ray, &w.pair_hit, &w.queue, &w.first, &w.mask, &w.ctr, &w.sched, &w.spill, &w.stream_buf, &w.flow}) b->release();
+		for (DevBuf* b : {&w.qent, &w.pair_hit, &w.seg, &w.first, &w.mask, &w.ctl, &w.spill, &w.stream_buf, &w.flow}) b->release();
 		if (w.flow_host) { (void)hipHostFree(w.flow_host); w.flow_host = nullptr; }
 		if (w.done) { (void)hipEventDestroy(w.done); w.done = nullptr; }
 		if (w.stream) { (void)hipStreamDestroy(w.stream); w.stream = nullptr; }
@@ -292,6 +298,20 @@ void* ptx_ctx_stream(ptx_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int ptx_ctx_synchronize(ptx_ctx* c) {
 	if (!c) return set_err(PTX_ERR_INVALID, "ctx is NULL");
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	return PTX_OK;
+}
+
+int ptx_ctx_set_timing(ptx_ctx* c, int on) {
+	if (!c) return set_err(PTX_ERR_INVALID, "ctx is NULL");
+	std::lock_guard<std::mutex> lk(c->mu);
+	c->timing_on = on != 0;
+	return PTX_OK;
+}
+
+int ptx_ctx_get_timing(ptx_ctx* c, ptx_kernel_timing* out) {
+	if (!c || !out) return set_err(PTX_ERR_INVALID, "NULL argument");
+	std::lock_guard<std::mutex> lk(c->mu);
+	*out = c->timing;
 	return PTX_OK;
 }
 
@@ -511,9 +531,12 @@ namespace {
 
 // Scenes the queue-based pipeline (wavefront.hip) takes: trees in global memory, a model of many surfaces (where the fused kernel's
 // waves run nearly empty), at most 64 surfaces (one mask word per ray). PTX_WAVEFRONT=0/1 overrides the choice (measurement).
-constexpr size_t kWfMaxPairs = 96u << 20;   // pairs the workspace of a batch-intersect slice is sized for: 48 B each + 4 B of queue
-constexpr uint64_t kWfRenderPairs = 768ull << 20;   // ... of a render slab (40 GB; the device has 288): slabs of 16 M paths on a 24-surface scene. Measured on the
-                                                    // atrium: 8 M-path slabs 300 Msamples/s, 16 M 325 — every step of a slab ends with a few waves finishing walks of hundreds of steps
+// Pair space is a pool sized from DEMAND: `wf_pairs_per_ray` of the scene (what its rays were seen to need; before the first
+// measurement min(surfaces, 4)) plus a margin decides how many rays a pool of `pool_pairs` serves; a step that needs more raises the
+// overflow word and the slab / slice is repeated in smaller pieces with the ratio it reported.
+constexpr uint64_t kWfPoolPairs = 128ull << 20;   // pairs of a render's pool (48 B each: 6 GB) — 16 M-path slabs on the 24-surface atrium (3.2 pairs per ray, two rays per path and step)
+constexpr uint64_t kWfBatchPairs = 32ull << 20;   // ... of a batch-intersect slice
+constexpr uint32_t kWfFlowWords = 64, kWfFlowRays = 58 /* 64-bit */, kWfFlowPeak = 60, kWfFlowOverflow = 63, kWfMaxRound = 56;   // flow words: [s] entries of step s of the round, then the pool's peak demand and the overflow word
 bool use_wavefront(const ptx_scene* sc) {
 	const size_t n_surf = sc->host.surfaces.size();
 	if (n_surf == 0 || n_surf > (size_t)kWfMaxSurfaces) return false;
@@ -524,22 +547,41 @@ bool use_wavefront(const ptx_scene* sc) {
 	if (const char* e = getenv("PTX_WAVEFRONT")) on = e[0] == '1';
 	return on;
 }
-hipError_t wf_workspace(ptx_ctx* c, int set, size_t rays, size_t n_surf, WfBuffers& W) {
+double wf_ratio_guess(const ptx_scene* sc) {
+	const double n_surf = (double)sc->host.surfaces.size();
+	if (sc->wf_pairs_per_ray > 0) return std::min(n_surf, sc->wf_pairs_per_ray * 1.15 + 0.05);
+	if (const char* e = getenv("PTX_WF_RATIO_GUESS")) return std::max(0.01, atof(e));   // tests: a guess that is too low exercises the overflow path
+	return std::min(n_surf, 4.0);
+}
+// buffers of one workspace set for `rays` rays per step, a pool of `pool` pairs and `steps` control blocks
+hipError_t wf_workspace(ptx_ctx* c, int set, size_t rays, size_t pool, size_t n_surf, size_t steps, WfBuffers& W) {
 	ptx_ctx::WfSet& w = c->wf[set];
-	const size_t pairs = rays * n_surf;
+	const size_t tiles = (rays + kWfTile - 1) / kWfTile;
 	hipError_t e;
-	if ((e = w.pair_ray.ensure(pairs * 32)) != hipSuccess) return e;
-	if ((e = w.pair_hit.ensure(pairs * 16)) != hipSuccess) return e;
-	if ((e = w.queue.ensure(pairs * 4)) != hipSuccess) return e;
+	if ((e = w.qent.ensure(pool * 32)) != hipSuccess) return e;
+	if ((e = w.pair_hit.ensure(pool * 16)) != hipSuccess) return e;
+	if ((e = w.seg.ensure(n_surf * tiles * sizeof(uint2))) != hipSuccess) return e;
 	if ((e = w.first.ensure(rays * 4)) != hipSuccess) return e;
 	if ((e = w.mask.ensure(rays * 8)) != hipSuccess) return e;
-	if ((e = w.ctr.ensure(kWfCtrBytes)) != hipSuccess) return e;
-	if ((e = w.sched.ensure(wf_sched_bytes(n_surf))) != hipSuccess) return e;
+	if ((e = w.ctl.ensure(steps * kWfCtlWords * 4)) != hipSuccess) return e;
+	if ((e = w.flow.ensure(kWfFlowWords * 4)) != hipSuccess) return e;
+	if (!w.flow_host && (e = hipHostMalloc((void**)&w.flow_host, kWfFlowWords * 4)) != hipSuccess) return e;
 	if ((e = w.spill.ensure((size_t)wf_traverse_grid(c->n_cu) * 4 * (size_t)kSpillWords * sizeof(uint2))) != hipSuccess) return e;
-	W.pair_ray = (float4*)w.pair_ray.p; W.pair_hit = (float4*)w.pair_hit.p; W.queue = (uint32_t*)w.queue.p;
-	W.queue_cap = (uint32_t)rays;
-	W.first = (uint32_t*)w.first.p; W.mask = (unsigned long long*)w.mask.p; W.ctr = (uint32_t*)w.ctr.p; W.sched = (uint32_t*)w.sched.p; W.spill = (uint2*)w.spill.p;
+	W.qent = (float4*)w.qent.p; W.pair_hit = (float4*)w.pair_hit.p;
+	W.pool_cap = (uint32_t)std::min<size_t>(pool, 0xFFFFFFFFu);
+	W.seg = (uint2*)w.seg.p; W.seg_cap = (uint32_t)tiles;
+	W.first = (uint32_t*)w.first.p; W.mask = (unsigned long long*)w.mask.p; W.ctl = (uint32_t*)w.ctl.p; W.spill = (uint2*)w.spill.p;
+	W.n_in = nullptr;
+	W.overflow = (uint32_t*)w.flow.p + kWfFlowOverflow;
+	W.peak = (uint32_t*)w.flow.p + kWfFlowPeak;
+	W.ray_counter = nullptr;
 	return hipSuccess;
+}
+size_t wf_workspace_bytes(const ptx_ctx* c) {
+	size_t b = 0;
+	for (const auto& w : c->wf)
+		for (const DevBuf* d : {&w.qent, &w.pair_hit, &w.seg, &w.first, &w.mask, &w.ctl, &w.spill, &w.stream_buf, &w.flow}) b += d->cap;
+	return b;
 }
 
 }  // namespace
@@ -580,8 +622,15 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 					for (uint32_t y = ya; y < yb; y++)
 						for (uint32_t x = xa; x < xb; x++) list.push_back((y - y0) * w + (x - x0));
 				}
+			// a previous render with stats == NULL and a device buffer returns without a sync (ptx.h): its generate / resolve kernels may
+			// still be reading the list this call is about to replace, and the context's stream is non-blocking (not ordered with the
+			// NULL stream a plain hipMemcpy would use) — drain it first, then upload on the same stream
+			HIP_TRY(hipStreamSynchronize(c->stream));
 			HIP_TRY(c->pixel_list.ensure(std::max<size_t>(list.size() * 4, 16)));
-			if (!list.empty()) HIP_TRY(hipMemcpy(c->pixel_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice));
+			if (!list.empty()) {
+				HIP_TRY(hipMemcpyAsync(c->pixel_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, c->stream));
+				HIP_TRY(hipStreamSynchronize(c->stream));   // `list` is a local
+			}
 			memcpy(c->list_key, key, sizeof key);
 			c->list_len = (uint32_t)list.size();
 		}
@@ -634,51 +683,75 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 			c->events.push_back(ev);
 		}
 	PassBuffers B{nullptr /* the fused kernel's streams: set below, once it is known which pipeline runs */, queue_stride, surface_units ? 1u : 0u, (float4*)c->sample_rad.p, (uint2*)c->spill.p, chunk_counter, ray_counter};
-	// queue-based pipeline (wavefront.hip): slab size from the pair budget — a step classifies two rays per path (extend + shadow)
+	// queue-based pipeline (wavefront.hip): a pass runs in slabs; slab size from the pair pool and the pairs a path of this scene was
+	// seen to need — a step classifies two rays per path (extend + shadow)
 	WfBuffers WF[2]{};
 	WfStream wf_st[2][2]{};
 	uint32_t wf_cap = 0;
 	int wf_sets = 1;
+	uint64_t pool_pairs = kWfPoolPairs;
+	const uint64_t pass_paths = (uint64_t)pass_spp * n_pixels;
+	const uint32_t wf_round = (uint32_t)std::min<uint64_t>((uint64_t)cfg->bounces + 1u, kWfMaxRound);   // steps enqueued back to back: a path of b bounces lives b steps + one for its last sun sample
+	const bool timing = stats && c->timing_on;
+	if (stats) c->timing = ptx_kernel_timing{};
+	auto slab_cap = [&]() -> uint32_t {   // paths of a slab: the pool must hold the pairs of its busiest step
+		const double per_path = 2.0 * wf_ratio_guess(sc);
+		const uint64_t by_pool = (uint64_t)std::max(65536.0, (double)pool_pairs / per_path);
+		return (uint32_t)std::min<uint64_t>({(pass_paths + wf_sets - 1) / wf_sets, (uint64_t)kWfMaxSlab - 1, by_pool});
+	};
 	if (wavefront) {
-		const uint64_t pass_paths = (uint64_t)pass_spp * n_pixels;
-		uint64_t pair_budget = kWfRenderPairs;
-		if (const char* e = getenv("PTX_WF_PAIRS_M")) pair_budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;   // measurement: workspace size in Mi pairs
-		wf_sets = getenv("PTX_WF_TWO_STREAMS") ? 2 : 1;   // measurement: two slabs side by side on two streams (neutral at 1080p, +45 % on 480x270 frames)
+		if (const char* e = getenv("PTX_WF_PAIRS_M")) pool_pairs = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;   // measurement: pool size in Mi pairs
+		pool_pairs = std::min<uint64_t>(pool_pairs, 0xFFFFFFFFull);
+		wf_sets = getenv("PTX_WF_TWO_STREAMS") ? 2 : 1;   // measurement: two slabs side by side on two streams
 		if (!c->wf_main_ev) HIP_TRY(hipEventCreateWithFlags(&c->wf_main_ev, hipEventDisableTiming));
 		auto allocate = [&]() -> hipError_t {
 			hipError_t e;
 			for (int k = 0; k < wf_sets; k++) {
 				ptx_ctx::WfSet& w = c->wf[k];
-				if ((e = wf_workspace(c, k, 2 * (size_t)wf_cap, n_surf, WF[k])) != hipSuccess) return e;
-				WF[k].ray_counter = ray_counter;
+				if ((e = wf_workspace(c, k, 2 * (size_t)wf_cap, pool_pairs, n_surf, wf_round, WF[k])) != hipSuccess) return e;
+				WF[k].ray_counter = (unsigned long long*)((uint32_t*)w.flow.p + kWfFlowRays);   // rays of the slab: added to the total once the slab is through (an overflowing attempt is not counted)
 				if ((e = w.stream_buf.ensure((size_t)wf_cap * 14 * sizeof(float4))) != hipSuccess) return e;
-				if ((e = w.flow.ensure(64)) != hipSuccess) return e;
-				if (!w.flow_host && (e = hipHostMalloc((void**)&w.flow_host, 64)) != hipSuccess) return e;
 				if (!w.stream && (e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking)) != hipSuccess) return e;
 				if (!w.done && (e = hipEventCreateWithFlags(&w.done, hipEventDisableTiming)) != hipSuccess) return e;
-				float4* base = (float4*)w.stream_buf.p;
-				wf_st[k][0] = WfStream{base, base + 8 * (size_t)wf_cap};
-				wf_st[k][1] = WfStream{base + 4 * (size_t)wf_cap, base + 11 * (size_t)wf_cap};
 			}
 			return hipSuccess;
 		};
-		// the pair space is sized for the worst case; when the device cannot spare that much, smaller slabs, and below 32 Mi pairs the fused kernel
+		// when the device cannot spare the pool: a smaller one (smaller slabs), and below 8 Mi pairs the fused kernel
 		for (;;) {
-			wf_cap = (uint32_t)std::min<uint64_t>({(pass_paths + wf_sets - 1) / wf_sets, (uint64_t)kWfMaxSlab - 1, std::max<uint64_t>(65536, pair_budget / (2 * (uint64_t)wf_sets * n_surf))});
+			wf_cap = slab_cap();
 			const hipError_t e = allocate();
 			if (e == hipSuccess) break;
 			if (e != hipErrorOutOfMemory) return set_err(PTX_ERR_HIP, std::string("queue-based pipeline workspace: ") + hipGetErrorString(e));
 			(void)hipGetLastError();
 			for (auto& w : c->wf)
-				for (DevBuf* b : {&w.pair_ray, &w.pair_hit, &w.queue, &w.first, &w.mask, &w.stream_buf}) b->release();
-			pair_budget /= 2;
-			if (pair_budget < (32ull << 20)) { wavefront = false; break; }
+				for (DevBuf* b : {&w.qent, &w.pair_hit, &w.seg, &w.first, &w.mask, &w.stream_buf}) b->release();
+			pool_pairs /= 2;
+			if (pool_pairs < (8ull << 20)) { wavefront = false; break; }
 		}
 	}
+	auto set_streams = [&](uint32_t cap) {   // the two stream buffers of each set, `cap` entries per array
+		for (int k = 0; k < wf_sets; k++) {
+			float4* base = (float4*)c->wf[k].stream_buf.p;
+			wf_st[k][0] = WfStream{base, base + 8 * (size_t)cap};
+			wf_st[k][1] = WfStream{base + 4 * (size_t)cap, base + 11 * (size_t)cap};
+		}
+	};
 	if (!wavefront) {
 		HIP_TRY(c->queues.ensure(n_slots * (size_t)queue_stride * sizeof(float4)));
 		B.queues = (float4*)c->queues.p;
 	}
+	size_t n_step_ev = 0;   // step events used so far (timing)
+	unsigned long long wf_rays = 0;   // rays the queue-based pipeline traced (slabs that went through)
+	auto step_events = [&]() -> hipEvent_t* {
+		if (!timing) return nullptr;
+		while (c->step_events.size() < n_step_ev + 4) {
+			hipEvent_t ev;
+			if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+			c->step_events.push_back(ev);
+		}
+		n_step_ev += 4;
+		return &c->step_events[n_step_ev - 4];
+	};
 	for (uint32_t p = 0; p < n_pass; p++) {
 		RenderParams P{};
 		P.W = cfg->W; P.H = cfg->H; P.x0 = x0; P.y0 = y0; P.w = w; P.h = h;
@@ -694,36 +767,77 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 		HIP_TRY(hipMemsetAsync(chunk_counter, 0, 8, c->stream));
 		if (stats) HIP_TRY(hipEventRecord(c->events[2 * p], c->stream));
 		if (wavefront) {
-			// queue-based pipeline: the pass in slabs of at most `wf_cap` paths, two at a time (one per workspace set and stream), each
-			// advanced step by step until no path is left
+			// queue-based pipeline: the pass in slabs of at most `wf_cap` paths (one per workspace set and stream at a time). The steps of a
+			// slab are enqueued back to back, `wf_round` at a time: every kernel takes its entry count from the device (flow words), and the
+			// host reads them back once per round — whether paths are left (pass-through materials can outlive bounces + 1 steps), whether
+			// some step's pairs overflowed the pool, and the peak demand that sizes the next slab.
 			HIP_TRY(hipEventRecord(c->wf_main_ev, c->stream));
 			for (int k = 0; k < wf_sets; k++) HIP_TRY(hipStreamWaitEvent(c->wf[k].stream, c->wf_main_ev, 0));
-			for (uint64_t first = 0; first < P.n_paths; first += (uint64_t)wf_sets * wf_cap) {
-				uint32_t n_in[2] = {0, 0}, slab_first[2] = {0, 0};
+			uint64_t first = 0;
+			while (first < P.n_paths) {
+				wf_cap = std::min(wf_cap, slab_cap());   // never above what the buffers were sized for
+				set_streams(wf_cap);
+				uint32_t n_slab[2] = {0, 0}, slab_first[2] = {0, 0};
+				bool live[2] = {false, false};
 				int cur[2] = {0, 0};
 				for (int k = 0; k < wf_sets; k++) {
 					const uint64_t f = first + (uint64_t)k * wf_cap;
 					slab_first[k] = (uint32_t)f;
-					n_in[k] = f < P.n_paths ? (uint32_t)std::min<uint64_t>(wf_cap, P.n_paths - f) : 0u;
-					if (n_in[k]) HIP_TRY(launch_wf_generate(sc->dev, P, wf_st[k][0], wf_cap, slab_first[k], n_in[k], B.sample_rad, c->wf[k].stream));
+					n_slab[k] = f < P.n_paths ? (uint32_t)std::min<uint64_t>(wf_cap, P.n_paths - f) : 0u;
+					if (!n_slab[k]) continue;
+					ptx_ctx::WfSet& ws = c->wf[k];
+					HIP_TRY(launch_wf_generate(sc->dev, P, wf_st[k][0], wf_cap, slab_first[k], n_slab[k], B.sample_rad, ws.stream));
+					HIP_TRY(hipMemsetAsync(ws.flow.p, 0, kWfFlowWords * 4, ws.stream));
+					HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ws.flow.p, (int)n_slab[k], 1, ws.stream));   // flow[0] = entries of step 0
+					live[k] = P.bounces > 0;
 				}
-				if (P.bounces == 0) continue;
-				while (n_in[0] || n_in[1]) {
-					bool launched[2] = {false, false};
+				bool overflow = false;
+				uint64_t peak = 0;
+				while (live[0] || live[1]) {
 					for (int k = 0; k < wf_sets; k++) {
-						if (!n_in[k]) continue;
-						ptx_ctx::WfSet& w = c->wf[k];
-						HIP_TRY(launch_wf_step(sc->dev, P, WF[k], wf_st[k][cur[k]], wf_st[k][cur[k] ^ 1], wf_cap, n_in[k], slab_first[k], (uint32_t*)w.flow.p, B.sample_rad, c->n_cu, w.stream));
-						HIP_TRY(hipMemcpyAsync(w.flow_host, w.flow.p, 4, hipMemcpyDeviceToHost, w.stream));
-						launched[k] = true;
+						if (!live[k]) continue;
+						ptx_ctx::WfSet& ws = c->wf[k];
+						uint32_t* flow = (uint32_t*)ws.flow.p;
+						HIP_TRY(hipMemsetAsync(ws.ctl.p, 0, (size_t)wf_round * kWfCtlWords * 4, ws.stream));
+						HIP_TRY(hipMemsetAsync(flow + 1, 0, (size_t)wf_round * 4, ws.stream));
+						for (uint32_t st = 0; st < wf_round; st++) {
+							WfBuffers W = WF[k];
+							W.ctl = (uint32_t*)ws.ctl.p + (size_t)st * kWfCtlWords;
+							W.n_in = flow + st;
+							HIP_TRY(launch_wf_step(sc->dev, P, W, wf_st[k][cur[k]], wf_st[k][cur[k] ^ 1], wf_cap, n_slab[k], slab_first[k], flow + st + 1, B.sample_rad, c->n_cu, ws.stream,
+							                       step_events()));
+							cur[k] ^= 1;
+						}
+						HIP_TRY(hipMemcpyAsync(ws.flow_host, flow, kWfFlowWords * 4, hipMemcpyDeviceToHost, ws.stream));
 					}
 					for (int k = 0; k < wf_sets; k++) {
-						if (!launched[k]) continue;
-						HIP_TRY(hipStreamSynchronize(c->wf[k].stream));
-						n_in[k] = *c->wf[k].flow_host;
-						cur[k] ^= 1;
+						if (!live[k]) continue;
+						ptx_ctx::WfSet& ws = c->wf[k];
+						HIP_TRY(hipStreamSynchronize(ws.stream));
+						peak = std::max<uint64_t>(peak, ws.flow_host[kWfFlowPeak]);
+						if (ws.flow_host[kWfFlowOverflow]) { overflow = true; live[k] = false; continue; }
+						const uint32_t left = ws.flow_host[wf_round];
+						if (left == 0) live[k] = false;
+						else HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ws.flow.p, (int)left, 1, ws.stream));   // next round: flow[0] = what this one left
 					}
+					if (overflow) break;
 				}
+				// what a ray of this scene needs, from the busiest step of these slabs (two rays per path and step)
+				const uint32_t n_big = std::max(n_slab[0], n_slab[1]);
+				if (peak && n_big) sc->wf_pairs_per_ray = std::max(sc->wf_pairs_per_ray, (double)peak / (2.0 * n_big));
+				if (stats) { c->timing.peak_pairs = std::max<uint64_t>(c->timing.peak_pairs, peak); c->timing.slab_paths = std::max<uint64_t>(c->timing.slab_paths, n_big); }
+				if (overflow) {
+					// some step needed more pairs than the pool holds: the same slabs again, smaller (the ratio just learnt says how much). The
+					// samples the aborted attempt already stored are stored again with the same values.
+					for (int k = 0; k < wf_sets; k++) HIP_TRY(hipStreamSynchronize(c->wf[k].stream));
+					const uint32_t smaller = std::min<uint32_t>(slab_cap(), wf_cap - wf_cap / 4);
+					if (wf_cap <= 4096) return set_err(PTX_ERR_HIP, "queue-based pipeline: the pair pool cannot hold one step of a 4096-path slab");
+					wf_cap = std::max<uint32_t>(4096, smaller);
+					continue;
+				}
+				for (int k = 0; k < wf_sets; k++)
+					if (n_slab[k] && P.bounces > 0) { unsigned long long r; memcpy(&r, c->wf[k].flow_host + kWfFlowRays, 8); wf_rays += r; }
+				first += (uint64_t)wf_sets * wf_cap;
 			}
 			for (int k = 0; k < wf_sets; k++) {
 				HIP_TRY(hipEventRecord(c->wf[k].done, c->wf[k].stream));
@@ -741,7 +855,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 	if (stats) {
 		unsigned long long rays = 0;
 		HIP_TRY(hipMemcpy(&rays, ray_counter, 8, hipMemcpyDeviceToHost));
-		stats->rays = rays;
+		stats->rays = rays + wf_rays;
 		stats->samples = (uint64_t)cfg->spp * n_pixels;
 		stats->passes = n_pass;
 		double ms = 0;
@@ -751,6 +865,19 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 			ms += t;
 		}
 		stats->kernel_ms = ms;
+		ptx_kernel_timing& tm = c->timing;
+		tm.pipeline = wavefront ? 1u : 0u;
+		tm.pool_pairs = wavefront ? pool_pairs : 0;
+		tm.workspace_bytes = wavefront ? wf_workspace_bytes(c) : c->queues.cap + c->spill.cap;
+		if (!wavefront) { tm.fused_ms = ms; tm.fused_launches = n_pass; }
+		for (size_t k = 0; k + 4 <= n_step_ev; k += 4) {
+			float t0 = 0, t1 = 0, t2 = 0;
+			HIP_TRY(hipEventElapsedTime(&t0, c->step_events[k], c->step_events[k + 1]));
+			HIP_TRY(hipEventElapsedTime(&t1, c->step_events[k + 1], c->step_events[k + 2]));
+			HIP_TRY(hipEventElapsedTime(&t2, c->step_events[k + 2], c->step_events[k + 3]));
+			tm.classify_ms += t0; tm.traverse_ms += t1; tm.shade_ms += t2;
+			tm.steps++;
+		}
 #ifdef PTX_PROF
 		unsigned long long prof[2 * kProfRegions];
 		HIP_TRY(hipMemcpy(prof, (char*)c->counters.p + 64, sizeof prof, hipMemcpyDeviceToHost));
@@ -802,29 +929,46 @@ int ptx_intersect_batch(ptx_scene* sc, const ptx_rays* r, size_t n, const ptx_hi
 		if (hh->u) { A.u = o + k * n; A.v = o + (k + 1) * n; }
 	}
 	if (use_wavefront(sc)) {
-		// queue-based pipeline, a slice of the batch at a time (the workspace is sized for every ray entering every surface)
+		// queue-based pipeline, a slice of the batch at a time: as many rays as the pool serves at the pairs per ray this scene was seen
+		// to need; a slice whose pairs do not fit is repeated smaller (the ratio it reported is remembered on the scene)
 		const size_t n_surf = sc->host.surfaces.size();
-		const size_t slice = std::min<size_t>(n, std::max<size_t>(65536, kWfMaxPairs / n_surf));
+		uint64_t pool_pairs = kWfBatchPairs;
+		if (const char* e = getenv("PTX_WF_PAIRS_M")) pool_pairs = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;
+		auto slice_cap = [&]() { return (size_t)std::max(16384.0, (double)pool_pairs / wf_ratio_guess(sc)); };
+		size_t slice = std::min<size_t>(n, slice_cap());
 		WfBuffers W{};
-		HIP_TRY(wf_workspace(c, 0, slice, n_surf, W));
-		for (size_t first = 0; first < n; first += slice) {
-			HIP_TRY(launch_wf_intersect(sc->dev, A, first, (uint32_t)std::min(slice, n - first), W, c->n_cu, c->stream));
-#ifdef PTX_WF_PROF
-			uint32_t ctr[192];
+		HIP_TRY(wf_workspace(c, 0, slice, pool_pairs, n_surf, 1, W));
+		ptx_ctx::WfSet& ws = c->wf[0];
+		for (size_t first = 0; first < n;) {
+			const uint32_t m = (uint32_t)std::min(slice, n - first);
+			HIP_TRY(hipMemsetAsync(ws.ctl.p, 0, kWfCtlWords * 4, c->stream));
+			HIP_TRY(hipMemsetAsync(ws.flow.p, 0, kWfFlowWords * 4, c->stream));
+			HIP_TRY(launch_wf_intersect(sc->dev, A, first, m, W, c->n_cu, c->stream));
+			HIP_TRY(hipMemcpyAsync(ws.flow_host, ws.flow.p, kWfFlowWords * 4, hipMemcpyDeviceToHost, c->stream));
 			HIP_TRY(hipStreamSynchronize(c->stream));
-			HIP_TRY(hipMemcpy(ctr, W.ctr, sizeof ctr, hipMemcpyDeviceToHost));
+			if (ws.flow_host[kWfFlowPeak]) sc->wf_pairs_per_ray = std::max(sc->wf_pairs_per_ray, (double)ws.flow_host[kWfFlowPeak] / (double)m);
+#ifdef PTX_WF_PROF
+			uint32_t ctl[kWfCtlCur];
+			HIP_TRY(hipMemcpy(ctl, W.ctl, sizeof ctl, hipMemcpyDeviceToHost));
+			const uint32_t* pr = ctl + kWfCtlProf;
 			static const char* names[8] = {"outer_round", "busy_round", "node_step", "tri_test", "hand_out", "unit_fetch", "pop", "stack_spill"};
-			fprintf(stderr, "WFPROF rays %zu pairs %u (%.2f per ray)\n", std::min(slice, n - first), ctr[0], (double)ctr[0] / (double)std::min(slice, n - first));
+			fprintf(stderr, "WFPROF rays %u pairs %u (%.2f per ray)\n", m, ctl[0], (double)ctl[0] / (double)m);
 			for (int k = 0; k < 8; k++)
-				fprintf(stderr, "WFPROF %-12s trips %10u lanes %11u  util %.3f  lanes/pair %.2f\n", names[k], ctr[160 + 2 * k], ctr[161 + 2 * k],
-				        ctr[160 + 2 * k] ? (double)ctr[161 + 2 * k] / (64.0 * ctr[160 + 2 * k]) : 0.0, (double)ctr[161 + 2 * k] / (double)ctr[0]);
+				fprintf(stderr, "WFPROF %-12s trips %10u lanes %11u  util %.3f  lanes/pair %.2f\n", names[k], pr[2 * k], pr[2 * k + 1],
+				        pr[2 * k] ? (double)pr[2 * k + 1] / (64.0 * pr[2 * k]) : 0.0, (double)pr[2 * k + 1] / (double)ctl[0]);
 			static const char* tn[6] = {"kernel", "unit_fetch", "hand_out", "pop", "descend", "leaf"};
 			fprintf(stderr, "WFHIST waves by log2(kilocycles of their run):");
-			for (int k = 0; k < 31; k++) if (ctr[128 + k]) fprintf(stderr, " [2^%d]=%u", k, ctr[128 + k]);
-			fprintf(stderr, "  waves that never had a busy round: %u\n", ctr[128 + 31]);
-			fprintf(stderr, "WFMAX slowest wave %u kcycles, most trips of a wave %u, longest walk of a lane %u steps\n", ctr[184], ctr[185], ctr[186]);
-			for (int k = 0; k < 6; k++) fprintf(stderr, "WFCLK %-10s %10u kcycles summed over waves (%.1f %%)\n", tn[k], ctr[176 + k], 100.0 * ctr[176 + k] / (double)ctr[176]);
+			for (int k = 0; k < 31; k++) if (pr[32 + k]) fprintf(stderr, " [2^%d]=%u", k, pr[32 + k]);
+			fprintf(stderr, "  waves that never had a busy round: %u\n", pr[32 + 31]);
+			fprintf(stderr, "WFMAX slowest wave %u kcycles, most trips of a wave %u, longest walk of a lane %u steps\n", pr[24], pr[25], pr[26]);
+			for (int k = 0; k < 6; k++) fprintf(stderr, "WFCLK %-10s %10u kcycles summed over waves (%.1f %%)\n", tn[k], pr[16 + k], 100.0 * pr[16 + k] / (double)pr[16]);
 #endif
+			if (ws.flow_host[kWfFlowOverflow]) {
+				if (slice <= 16384) return set_err(PTX_ERR_HIP, "queue-based pipeline: the pair pool cannot hold a 16384-ray slice");
+				slice = std::max<size_t>(16384, std::min(slice_cap(), slice - slice / 4));
+				continue;   // the same rays again, fewer at a time
+			}
+			first += m;
 		}
 	} else {
 		const int grid = (int)std::min<size_t>((size_t)c->n_cu, (n + kBlock - 1) / kBlock);
@@ -863,6 +1007,33 @@ int ptx_pbr_eval_batch(ptx_ctx* c, const float* in, size_t n, float* out) {
 	HIP_TRY(launch_pbr_eval(d_in, d_out, n, c->stream));
 	if (!dev) {
 		HIP_TRY(hipMemcpyAsync(out, d_out, n * 15 * 4, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	return PTX_OK;
+}
+
+int ptx_camera_rays_batch(ptx_scene* sc, const float* ndc_ratio, size_t n, float* rays) {
+	if (!sc) return set_err(PTX_ERR_INVALID, "ptx_camera_rays_batch: scene is NULL");
+	if (!sc->ctx) return set_err(PTX_ERR_NO_DEVICE, "ptx_camera_rays_batch: scene was created without a GPU context (no CPU path exists)");
+	if (n == 0) return PTX_OK;
+	if (!ndc_ratio || !rays) return set_err(PTX_ERR_INVALID, "ptx_camera_rays_batch: NULL argument");
+	ptx_ctx* c = sc->ctx;
+	std::lock_guard<std::mutex> lk(c->mu);
+	HIP_TRY(hipSetDevice(c->device));
+	const bool dev = is_device_ptr(ndc_ratio);
+	if (dev != is_device_ptr(rays)) return set_err(PTX_ERR_INVALID, "ptx_camera_rays_batch: in and out must both be device or both be host memory");
+	const float* d_in = ndc_ratio;
+	float* d_out = rays;
+	if (!dev) {
+		HIP_TRY(c->stage_a.ensure(n * 3 * 4));
+		HIP_TRY(c->stage_b.ensure(n * 6 * 4));
+		HIP_TRY(hipMemcpyAsync(c->stage_a.p, ndc_ratio, n * 3 * 4, hipMemcpyHostToDevice, c->stream));
+		d_in = (const float*)c->stage_a.p;
+		d_out = (float*)c->stage_b.p;
+	}
+	HIP_TRY(launch_camera_rays(sc->dev, d_in, d_out, n, c->stream));
+	if (!dev) {
+		HIP_TRY(hipMemcpyAsync(rays, d_out, n * 6 * 4, hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
 	return PTX_OK;

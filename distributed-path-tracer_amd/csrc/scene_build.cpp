@@ -18,7 +18,9 @@
 #include <deque>
 #include <limits>
 #include <atomic>
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <tuple>
 
@@ -146,10 +148,17 @@ struct MeshBuilder {
 		std::vector<uint32_t>().swap(ids);
 		if (par_levels > 0 && !lids.empty() && !rids.empty() && lids.size() + rids.size() >= 16384) {
 			MeshBuilder sub{pa, pb, pc, {}, 0};
-			std::thread th([&] { sub.build(l, std::move(lids), levels_left - 1, depth + 1, par_levels - 1); });
+			// an exception on either side (std::bad_alloc on a huge mesh) must not unwind past a joinable thread: the helper's is
+			// carried over in `sub_err`, the thread is always joined, and whichever came first is rethrown on this thread
+			std::exception_ptr sub_err;
+			std::thread th([&] {
+				try { sub.build(l, std::move(lids), levels_left - 1, depth + 1, par_levels - 1); } catch (...) { sub_err = std::current_exception(); }
+			});
+			struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_guard{th};
 			const int32_t c = build(r, std::move(rids), levels_left - 1, depth + 1, par_levels - 1);
 			nodes[me].right = c;
 			th.join();
+			if (sub_err) std::rethrow_exception(sub_err);
 			const int32_t off = (int32_t)nodes.size();
 			nodes.reserve(nodes.size() + sub.nodes.size());
 			for (BuildNode& bn : sub.nodes) {
@@ -242,19 +251,33 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 		int par_levels = 0;   // 2^par_levels subtree tasks per surface when surfaces alone do not fill the threads
 		while (n_surf && (n_surf << par_levels) < n_threads && par_levels < 5) par_levels++;
 		std::atomic<size_t> next_surface{0};
+		std::mutex err_mu;
+		std::exception_ptr first_err;   // an exception inside a pool thread would terminate the process: keep the first, rethrow after the joins
 		auto worker = [&] {
-			for (size_t si = next_surface++; si < n_surf; si = next_surface++) {
-				const int32_t nt = s.surf_range[8 * si + 3];
-				sb[si].tree.reset(new MeshBuilder{sb[si].pa, sb[si].pb, sb[si].pc, {}, 0});
-				std::vector<uint32_t> all(nt);
-				for (int32_t t = 0; t < nt; t++) all[t] = (uint32_t)t;
-				sb[si].tree->build(sb[si].box, std::move(all), 25, 1, par_levels);  // mesh.hpp:34: max_depth = 25
+			try {
+				for (size_t si = next_surface++; si < n_surf; si = next_surface++) {
+					const int32_t nt = s.surf_range[8 * si + 3];
+					sb[si].tree.reset(new MeshBuilder{sb[si].pa, sb[si].pb, sb[si].pc, {}, 0});
+					std::vector<uint32_t> all(nt);
+					for (int32_t t = 0; t < nt; t++) all[t] = (uint32_t)t;
+					sb[si].tree->build(sb[si].box, std::move(all), 25, 1, par_levels);  // mesh.hpp:34: max_depth = 25
+				}
+			} catch (...) {
+				std::lock_guard<std::mutex> lk(err_mu);
+				if (!first_err) first_err = std::current_exception();
+				next_surface = n_surf;   // the other workers stop at their next fetch
 			}
 		};
 		std::vector<std::thread> pool;
-		for (unsigned k = 1; k < std::min<size_t>(n_threads, n_surf); k++) pool.emplace_back(worker);
+		try {
+			for (unsigned k = 1; k < std::min<size_t>(n_threads, n_surf); k++) pool.emplace_back(worker);
+		} catch (...) {   // thread creation failed: the ones that exist still run to the end
+			std::lock_guard<std::mutex> lk(err_mu);
+			if (!first_err) first_err = std::current_exception();
+		}
 		worker();
 		for (std::thread& t : pool) t.join();
+		if (first_err) std::rethrow_exception(first_err);
 	}
 	for (size_t si = 0; si < n_surf; si++) {
 		int32_t* rg = &s.surf_range[8 * si];

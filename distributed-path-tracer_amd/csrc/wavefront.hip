@@ -6,35 +6,29 @@
 // fetch from L2 / HBM: the measured result is 6 % of the lanes on in the tree loops and 56 % of the wave-cycles parked on
 // s_waitcnt (profiles/round2_pmc_atrium*.txt). Here the unit of work is the PAIR (ray, surface it enters):
 //   k_wf_classify  one ray per lane: local ray per model space, model box, surface boxes (scene::model::intersect, model.cpp:27-60;
-//                  core::mesh::intersect's box test, mesh.cpp:308-315) -> the ray's pairs, appended to one queue per surface
+//                  core::mesh::intersect's box test, mesh.cpp:308-315) -> the ray's pairs, written as queue entries (local ray + result
+//                  slot) grouped by surface: pair space comes from a pool sized by demand, one reservation per tile of 1024 rays
 //   k_wf_traverse  persistent waves that eat the queues: every lane walks ONE pair's tree (core::mesh::intersect, mesh.cpp:300-405)
 //                  and takes the next pair as soon as its walk ends, so lanes stay busy whatever the walk lengths; 256-thread
-//                  blocks and a traversal-only register footprint give 8 waves per SIMD (twice the fused kernel's) to cover the
-//                  fetch latency; queues are dealt to XCDs surface by surface so that each L2 sees a part of the geometry
-//   k_wf_merge_*   one ray per lane again: the ray's pair results in surface order = model::intersect's loop (first surface wins
-//                  ties on the local distance), then renderer::intersect's loop over models (first model wins ties on the world
-//                  distance, renderer.cpp:663-669)
+//                  blocks and a traversal-only register footprint give 5 waves per SIMD to cover the fetch latency; queues are
+//                  dealt to XCDs surface by surface so that each L2 sees a part of the geometry
+//   k_wf_merge_* / k_wf_shade   one ray per lane again: the ray's pair results in surface order = model::intersect's loop (first
+//                  surface wins ties on the local distance), then renderer::intersect's loop over models (first model wins ties on the
+//                  world distance, renderer.cpp:663-669)
+// The entry count of a step lives on the device (flow words): the host enqueues all steps of a slab without reading anything back.
 // Every arithmetic operation on a ray is the one the fused kernel performs (same device functions); only where and when it
 // happens differs, so results are bitwise those of the fused kernel and of the reference.
 #include "device_core.hpp"
 
 namespace ptx {
 
-// Tunables (the -D overrides are for tools/build_variant.sh A/B builds; measured values in profiles/round2_wf_ab.txt)
+// Tunables (the -D overrides are for tools/build_variant.sh A/B builds; measured values in profiles/round2_wf_ab.txt, round3_wf_ab.txt)
 constexpr int kWfBlock = 256;              // threads per workgroup of the traverse / shade / merge kernels
-constexpr int kWfClassifyBlock = 1024;     // ... of the classify kernel: queue space is reserved per workgroup
+constexpr int kWfClassifyBlock = (int)kWfTile;   // ... of the classify kernel: pair space is reserved per tile of 1024 rays
 #ifndef PTX_WF_UNIT
 #define PTX_WF_UNIT 64
 #endif
 constexpr uint32_t kWfUnit = PTX_WF_UNIT;  // queue entries a wave stages into its LDS slice at a time
-#ifndef PTX_WF_GRAB
-#define PTX_WF_GRAB 256
-#endif
-constexpr uint32_t kWfGrab = PTX_WF_GRAB;  // most queue entries a wave reserves per atomic (a multiple of kWfUnit) ...
-#ifndef PTX_WF_GUIDE_DIV
-#define PTX_WF_GUIDE_DIV 32
-#endif
-constexpr uint32_t kWfGuideDiv = PTX_WF_GUIDE_DIV;   // ... and the share of the stripe's remaining entries it reserves (about 1 / waves that work on a stripe)
 #ifndef PTX_WF_LDS_STACK
 #define PTX_WF_LDS_STACK 8
 #endif
@@ -44,11 +38,7 @@ constexpr int kWfLdsStack = PTX_WF_LDS_STACK;         // traversal-stack levels 
 #endif
 constexpr uint32_t kWfRefillMin = PTX_WF_REFILL_MIN;   // idle lanes that make a hand-out of new pairs worth its instructions
 
-// counters block (uint32): [0] pairs allocated, [kWfCtrLen + u] entries in queue u
-constexpr uint32_t kWfCtrLen = 64;
-
-// PTX_WF_PROF builds: wave-level trips and active lanes per region of k_wf_traverse, added into ctr[kWfCtrProf ..] (measurement only)
-[[maybe_unused]] constexpr uint32_t kWfCtrProf = 160;
+// PTX_WF_PROF builds: wave-level trips and active lanes per region of k_wf_traverse, added into ctl[kWfCtlProf ..] (measurement only)
 #ifdef PTX_WF_PROF
 #define WFPROF(k) do { const uint64_t m_ = __ballot(true); pl[k] += 1u; pt[k] += (lane == (uint32_t)(__ffsll((long long)m_) - 1)) ? 1u : 0u; if ((k) == 2 || (k) == 3) walk_steps++; } while (0)
 // wave-level clock spent per region (kilocycles, lane 0 adds it up): T0 / T1 bracket a region executed under wave-uniform control flow
@@ -71,115 +61,146 @@ DEV void to_space(const SpaceRec& SP, V3 o, V3 d, V3& lo, V3& ld, V3& inv) {
 }
 
 // ------------------------------------------------------------------------------------ classify
-// Ray sources: ray `i` of a launch is (o, d) when valid(i)
+// Ray sources: ray `i` of a step with `m` entries is (o, d) when valid(i, m); the step has count(m) rays
 struct SoaRays {
 	const float *ox, *oy, *oz, *dx, *dy, *dz;
-	DEV bool valid(uint32_t) const { return true; }
-	DEV void load(uint32_t i, V3& o, V3& d) const { o = mk(ox[i], oy[i], oz[i]); d = mk(dx[i], dy[i], dz[i]); }
+	DEV uint32_t count(uint32_t m) const { return m; }
+	DEV bool valid(uint32_t, uint32_t) const { return true; }
+	DEV void load(uint32_t i, uint32_t, V3& o, V3& d) const { o = mk(ox[i], oy[i], oz[i]); d = mk(dx[i], dy[i], dz[i]); }
 };
 
+// One tile = 1024 consecutive rays, one ray per lane: local ray per model space, model box, surface boxes (scene::model::intersect,
+// model.cpp:27-60; core::mesh::intersect's box test, mesh.cpp:308-315) -> a 64-bit mask of entered surfaces per ray. The tile reserves
+// its pairs with one atomic; inside its block of the pool the queue entries are grouped by surface (one segment per surface, published
+// in that surface's segment list), the result slots by ray. Persistent workgroups loop over the tiles of the step: the entry count of
+// a step is only known on the device.
 template <class Src>
-__global__ void __launch_bounds__(kWfClassifyBlock) k_wf_classify(DevScene S0, Src src, uint32_t n, WfBuffers W, const ModelRec* __restrict__ t_models,
+__global__ void __launch_bounds__(kWfClassifyBlock) k_wf_classify(DevScene S0, Src src, uint32_t n_host, WfBuffers W, const ModelRec* __restrict__ t_models,
                                                          const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces,
                                                          const uint32_t* __restrict__ t_model_space) {
 	DevScene S = S0;
 	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;   // scalar-loaded tables (device_core.hpp: Tables)
-	__shared__ uint32_t s_cnt[kWfMaxSurfaces], s_base[kWfMaxSurfaces], s_wave_total[kWfClassifyBlock / 64];
+	__shared__ uint32_t s_cnt[kWfMaxSurfaces], s_off[kWfMaxSurfaces], s_wave_first[kWfClassifyBlock / 64];
+	__shared__ uint32_t s_rays, s_base, s_over;
 	const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-	__shared__ uint32_t s_rays;
-	if (threadIdx.x < (uint32_t)kWfMaxSurfaces) s_cnt[threadIdx.x] = 0;
-	if (threadIdx.x == 0) s_rays = 0;
-	__syncthreads();
-	const uint32_t i = blockIdx.x * kWfClassifyBlock + threadIdx.x;
-	const bool active = i < n && src.valid(i);
-	V3 o = {0, 0, 0}, d = {0, 0, 1};
-	if (active) src.load(i, o, d);
+	const uint32_t m_in = W.n_in ? *W.n_in : n_host;
+	const uint32_t n = src.count(m_in);
+	for (uint32_t tile = blockIdx.x; (uint64_t)tile * kWfTile < (uint64_t)n; tile += gridDim.x) {
+		if (threadIdx.x < (uint32_t)kWfMaxSurfaces) s_cnt[threadIdx.x] = 0;
+		if (threadIdx.x == 0) s_rays = 0;
+		__syncthreads();
+		const uint32_t i = tile * kWfTile + threadIdx.x;
+		const bool active = i < n && src.valid(i, m_in);
+		V3 o = {0, 0, 0}, d = {0, 0, 1};
+		if (active) src.load(i, m_in, o, d);
 
-	// pass 1: the surfaces this ray enters (bit u of `mine`), and per surface the number of rays of this wave that enter it (lane u of `cnt`)
-	unsigned long long mine = 0;
-	uint32_t cnt = 0;
-	{
-		uint32_t cur_space = 0xFFFFFFFFu;
-		V3 lo = o, ld = d, inv = d;
-		for (int m = 0; m < S.n_models; m++) {
-			const ModelRec& M = S.models[m];
-			const uint32_t spc = S.model_space[m];
-			if (spc != cur_space) { to_space(S.spaces[spc], o, d, lo, ld, inv); cur_space = spc; }
-			float nr, fr;
-			const bool enters = active && aabb_test_inv(M.bmin, M.bmax, lo, inv, nr, fr);   // model box first (model.cpp:38-40)
-			if (__ballot(enters) == 0) continue;
-			for (int k = 0; k < M.n_surfaces; k++) {
-				const int u = M.first_surface + k;
-				const SurfaceRec& sf = S.surfaces[u];
-				const bool ent = enters && aabb_test_inv(sf.bmin, sf.bmax, lo, inv, nr, fr);
-				const uint64_t em = __ballot(ent);
-				if (em == 0) continue;
-				if (ent) mine |= 1ull << u;
-				cnt = (int)lane == u ? (uint32_t)__popcll(em) : cnt;
-			}
-		}
-	}
-	// pair slots: the pairs of a ray are consecutive, in surface order. Reservations are made per WORKGROUP (one global atomic per
-	// surface and one for the pair space per 1024 rays): per-wave atomics on two dozen addresses serialise in L2 and cost more than
-	// the box tests (measured: 0.87 ms per 4 M rays with per-wave atomics)
-	const uint32_t mycnt = (uint32_t)__popcll(mine);
-	uint32_t incl = mycnt;
-	for (uint32_t off = 1; off < 64; off <<= 1) {
-		const uint32_t t = __shfl_up(incl, off);
-		if (lane >= off) incl += t;
-	}
-	const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-	uint32_t woff = 0;   // lane u: where this wave's entries start inside the workgroup's reservation of queue u
-	if (cnt) woff = atomicAdd(&s_cnt[lane], cnt);
-	if (lane == 0) s_wave_total[wave] = total;
-	if (W.ray_counter) {   // rays traced (stats): one atomic per workgroup
-		const uint32_t nv = (uint32_t)__popcll(__ballot(active));
-		if (lane == 0 && nv) atomicAdd(&s_rays, nv);
-	}
-	__syncthreads();
-	if (W.ray_counter && threadIdx.x == 0 && s_rays) atomicAdd(W.ray_counter, (unsigned long long)s_rays);
-	if (wave == 0) {
-		if (lane < (uint32_t)kWfMaxSurfaces && s_cnt[lane]) s_base[lane] = atomicAdd(&W.ctr[kWfCtrLen + lane], s_cnt[lane]);
-		uint32_t t = lane < (uint32_t)(kWfClassifyBlock / 64) ? s_wave_total[lane] : 0u, ex = t;
-		for (uint32_t off = 1; off < (uint32_t)(kWfClassifyBlock / 64); off <<= 1) {
-			const uint32_t v = __shfl_up(ex, off);
-			if (lane >= off) ex += v;
-		}
-		const uint32_t block_total = __builtin_amdgcn_readlane(ex, kWfClassifyBlock / 64 - 1);
-		uint32_t base = 0;
-		if (lane == 0 && block_total) base = atomicAdd(&W.ctr[0], block_total);
-		base = __builtin_amdgcn_readfirstlane(base);
-		if (lane < (uint32_t)(kWfClassifyBlock / 64)) s_wave_total[lane] = base + ex - t;   // now: first pair of the wave
-	}
-	__syncthreads();
-	const uint32_t first = s_wave_total[wave] + incl - mycnt;
-	if (i < n) { W.first[i] = first; W.mask[i] = mine; }
-	const uint32_t qb = cnt ? s_base[lane] + woff : 0u;
-
-	// pass 2: write the pairs (local ray + surface) and their queue entries
-	{
-		uint32_t cur_space = 0xFFFFFFFFu;
-		V3 lo = o, ld = d, inv = d;
-		for (int m = 0; m < S.n_models; m++) {
-			const ModelRec& M = S.models[m];
-			const unsigned long long range = (M.n_surfaces >= 64 ? ~0ull : ((1ull << M.n_surfaces) - 1ull)) << M.first_surface;
-			if (__ballot((mine & range) != 0) == 0) continue;
-			const uint32_t spc = S.model_space[m];
-			if (spc != cur_space) { to_space(S.spaces[spc], o, d, lo, ld, inv); cur_space = spc; }
-			for (int k = 0; k < M.n_surfaces; k++) {
-				const int u = M.first_surface + k;
-				const bool bit = (mine >> u) & 1ull;
-				const uint64_t em = __ballot(bit);
-				if (em == 0) continue;
-				const uint32_t b = __builtin_amdgcn_readlane(qb, u);
-				if (bit) {
-					const uint32_t p = first + (uint32_t)__popcll(mine & ((1ull << u) - 1ull));
-					W.queue[(size_t)u * W.queue_cap + b + rank_in(em)] = p;
-					W.pair_ray[2 * (size_t)p] = make_float4(lo.x, lo.y, lo.z, __int_as_float(u));
-					W.pair_ray[2 * (size_t)p + 1] = make_float4(ld.x, ld.y, ld.z, 0.f);
+		// pass 1: the surfaces this ray enters (bit u of `mine`), and per surface the number of rays of this wave that enter it (lane u of `cnt`)
+		unsigned long long mine = 0;
+		uint32_t cnt = 0;
+		{
+			uint32_t cur_space = 0xFFFFFFFFu;
+			V3 lo = o, ld = d, inv = d;
+			for (int m = 0; m < S.n_models; m++) {
+				const ModelRec& M = S.models[m];
+				const uint32_t spc = S.model_space[m];
+				if (spc != cur_space) { to_space(S.spaces[spc], o, d, lo, ld, inv); cur_space = spc; }
+				float nr, fr;
+				const bool enters = active && aabb_test_inv(M.bmin, M.bmax, lo, inv, nr, fr);   // model box first (model.cpp:38-40)
+				if (__ballot(enters) == 0) continue;
+				for (int k = 0; k < M.n_surfaces; k++) {
+					const int u = M.first_surface + k;
+					const SurfaceRec& sf = S.surfaces[u];
+					const bool ent = enters && aabb_test_inv(sf.bmin, sf.bmax, lo, inv, nr, fr);
+					const uint64_t em = __ballot(ent);
+					if (em == 0) continue;
+					if (ent) mine |= 1ull << u;
+					cnt = (int)lane == u ? (uint32_t)__popcll(em) : cnt;
 				}
 			}
 		}
+		// result slots: the pairs of a ray are consecutive, in surface order. Reservations are made per TILE (one global atomic for the
+		// pair space, one per entered surface for its segment list): per-wave atomics on two dozen addresses serialise in L2 and cost
+		// more than the box tests (measured: 0.87 ms per 4 M rays with per-wave atomics)
+		const uint32_t mycnt = (uint32_t)__popcll(mine);
+		uint32_t incl = mycnt;
+		for (uint32_t off = 1; off < 64; off <<= 1) {
+			const uint32_t t = __shfl_up(incl, off);
+			if (lane >= off) incl += t;
+		}
+		const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+		uint32_t woff = 0;   // lane u: where this wave's entries start inside the tile's segment of surface u
+		if (cnt) woff = atomicAdd(&s_cnt[lane], cnt);
+		if (lane == 0) s_wave_first[wave] = total;
+		if (W.ray_counter) {   // rays traced (stats): one atomic per tile
+			const uint32_t nv = (uint32_t)__popcll(__ballot(active));
+			if (lane == 0 && nv) atomicAdd(&s_rays, nv);
+		}
+		__syncthreads();
+		if (W.ray_counter && threadIdx.x == 0 && s_rays) atomicAdd(W.ray_counter, (unsigned long long)s_rays);
+		if (wave == 0) {
+			// lane u: entries of surface u in this tile, and where its segment starts inside the tile's block (exclusive prefix)
+			const uint32_t c = s_cnt[lane];
+			uint32_t cx = c;
+			for (uint32_t off = 1; off < 64; off <<= 1) {
+				const uint32_t v = __shfl_up(cx, off);
+				if (lane >= off) cx += v;
+			}
+			const uint32_t block_total = __builtin_amdgcn_readlane(cx, 63);
+			s_off[lane] = cx - c;
+			// lane w: result slots of wave w start at ... (exclusive prefix of the waves' totals)
+			uint32_t t = lane < (uint32_t)(kWfClassifyBlock / 64) ? s_wave_first[lane] : 0u, ex = t;
+			for (uint32_t off = 1; off < (uint32_t)(kWfClassifyBlock / 64); off <<= 1) {
+				const uint32_t v = __shfl_up(ex, off);
+				if (lane >= off) ex += v;
+			}
+			uint32_t base = 0;
+			if (lane == 0 && block_total) base = atomicAdd(&W.ctl[0], block_total);
+			base = __builtin_amdgcn_readfirstlane(base);
+			// the pool is sized from demand: a tile whose pairs do not fit writes none, raises the overflow word, and the host repeats
+			// the slab in smaller pieces (64-bit sum: `base` keeps growing after the pool is full)
+			const bool over = (uint64_t)base + block_total > (uint64_t)W.pool_cap;
+			if (lane < (uint32_t)(kWfClassifyBlock / 64)) s_wave_first[lane] = base + ex - t;
+			if (lane == 0) {
+				s_base = base; s_over = over ? 1u : 0u;
+				if (over) { W.ctl[1] = 1u; *W.overflow = 1u; }
+			}
+			if (!over && c) {   // publish this tile's segment of surface `lane`
+				const uint32_t k = atomicAdd(&W.ctl[kWfCtlSeg + lane], 1u);
+				W.seg[(size_t)lane * W.seg_cap + k] = make_uint2(base + (cx - c), c);
+			}
+		}
+		__syncthreads();
+		const bool over = s_over != 0;
+		const uint32_t first = s_wave_first[wave] + incl - mycnt;
+		if (i < n) { W.first[i] = over ? 0u : first; W.mask[i] = over ? 0ull : mine; }
+		const uint32_t qb = cnt ? s_base + s_off[lane] + woff : 0u;   // lane u: first queue entry of this wave in the tile's segment of surface u
+
+		// pass 2: the queue entries (local ray + result slot), grouped by surface
+		if (!over) {
+			uint32_t cur_space = 0xFFFFFFFFu;
+			V3 lo = o, ld = d, inv = d;
+			for (int m = 0; m < S.n_models; m++) {
+				const ModelRec& M = S.models[m];
+				const unsigned long long range = (M.n_surfaces >= 64 ? ~0ull : ((1ull << M.n_surfaces) - 1ull)) << M.first_surface;
+				if (__ballot((mine & range) != 0) == 0) continue;
+				const uint32_t spc = S.model_space[m];
+				if (spc != cur_space) { to_space(S.spaces[spc], o, d, lo, ld, inv); cur_space = spc; }
+				for (int k = 0; k < M.n_surfaces; k++) {
+					const int u = M.first_surface + k;
+					const bool bit = (mine >> u) & 1ull;
+					const uint64_t em = __ballot(bit);
+					if (em == 0) continue;
+					const uint32_t b = __builtin_amdgcn_readlane(qb, u);
+					if (bit) {
+						const uint32_t slot = first + (uint32_t)__popcll(mine & ((1ull << u) - 1ull));
+						const size_t e = (size_t)b + rank_in(em);
+						W.qent[2 * e] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(slot));
+						W.qent[2 * e + 1] = make_float4(ld.x, ld.y, ld.z, 0.f);
+					}
+				}
+			}
+		}
+		__syncthreads();   // the next tile resets what this one still reads
 	}
 }
 
@@ -194,15 +215,21 @@ DEV int wf_surface_at(uint32_t xcd, uint32_t r, uint32_t n_surf) {
 	return u < n_surf ? (int)u : -1;
 }
 
+// Persistent 256-thread workgroups (94 VGPRs, no scratch, 5 waves per SIMD). Every lane walks ONE pair's tree (mesh.cpp:300-405, the
+// loop of mesh_traverse) and takes its next pair from the wave's LDS-staged unit as soon as the walk ends. A wave takes work one
+// SEGMENT (the entries one classify tile queued for one surface: contiguous, <= 1024) at a time with one atomic on the surface's
+// cursor, and stages it in units of 64 entries with coalesced loads — the entries carry the local ray and the result slot, nothing
+// is gathered.
 #ifdef PTX_WF_WAVES
 __attribute__((amdgpu_waves_per_eu(PTX_WF_WAVES, PTX_WF_WAVES)))
 #endif
 __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers W, const SurfaceRec* __restrict__ t_surfaces) {
 	DevScene S = S0;
 	S.surfaces = t_surfaces;
+	if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(W.peak, W.ctl[0]);   // demand of this step (counted on even when it overflowed the pool)
+	if (W.ctl[1]) return;   // this step's pairs did not fit the pool: the host repeats the slab
 	const Geom g = {S.nodes, S.refs, S.tri_isect, S.glb_leaf_ordered != 0, true};
 	__shared__ float4 s_ray[kWfBlock / 64][kWfUnit][2];
-	__shared__ uint32_t s_pair[kWfBlock / 64][kWfUnit];
 	// Pending subtrees beyond the register levels. A store to global memory here would sit in the same in-order counter as the node
 	// fetches (gfx9 has one vmcnt for loads and stores): 4 of 10 node steps on these trees push deeper than the registers hold, and each
 	// would make the next fetch wait for a write acknowledgement. LDS has its own counter and a tenth of the latency.
@@ -221,15 +248,13 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 	const uint32_t n_surf = S.n_surfaces;
 	const uint32_t n_order = ((n_surf + 7u) / 8u) * 8u;
 
-	// wave-uniform: the unit being handed out
-	uint32_t unit_pos = 0, unit_end = 0, unit_base = 0, order_pos = 0, grab_pos = 0, grab_end = 0;
-	const uint32_t stripe0 = (blockIdx.x / 8u) * (kWfBlock / 64) + wave;   // where this wave starts in a queue: the waves of an XCD spread over the stripes
+	// wave-uniform: the segment being handed out, and the unit of it staged in LDS
+	uint32_t seg_pos = 0, seg_end = 0, unit_pos = 0, unit_n = 0, order_pos = 0;
 	int unit_surf = -1;
-	bool more = true, stripe_open = false, queue_done = false;
-	uint32_t stripe_cur = 0, stripe_lo = 0, stripe_hi = 0, stripe_rem = 0, stripe_n = 0;   // the stripe this wave is reserving from
+	bool more = true;
 	// per lane: the walk in progress (core::mesh::intersect's locals, as in mesh_traverse)
 	bool busy = false, have = false;
-	uint32_t pair = 0, node = 0;
+	uint32_t slot = 0, node = 0;
 	int sp = 0;
 	uint32_t n0 = 0, n1 = 0, n2 = 0;
 	float m0 = 0, m1 = 0, m2 = 0;
@@ -246,88 +271,46 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 		WFPROF(0);
 		const uint64_t idle_m = __ballot(!busy);
 		if (more && ((uint32_t)__popcll(idle_m) >= kWfRefillMin || ~idle_m == 0)) {
-			if (unit_pos == unit_end) {
+			if (unit_pos == unit_n) {
 				WFT0();
-				// next unit: the rest of this wave's grab, else a new grab — this XCD's queues first. A queue is handed out in kWfStripes
-				// contiguous stripes, each with its own counter in its own 256 bytes (one counter per queue, two dozen of them in one cache
-				// line, made every hand-out of the chip queue up in one L2 channel: units of 32 / 64 / 128 entries ran at 656 / 1000 /
-				// 1306 Mrays/s). Reads of these words serialise in L2 like the atomics do, so a wave reads as little as it can: a grab is
-				// ONE atomic on the wave's current stripe (what it returns says how much the stripe still holds); the wave whose grab takes
-				// a stripe's last entry counts the stripe closed, the one that closes a queue's last stripe sets the queue's bit in one
-				// mask word — a wave looking for work reads that word, then the 16 counters of one open queue, and a wave that finds the
-				// mask full is done after one read (with every wave polling every stripe counter, a launch of FOUR pairs took 1 ms).
-				if (grab_pos == grab_end) {
-					unsigned long long* const closed_mask = reinterpret_cast<unsigned long long*>(W.sched + (size_t)n_surf * (kWfStripes + 1u) * kWfSchedStride);
+				if (seg_pos == seg_end) {
+					// next segment: this XCD's surfaces first; one atomic on the surface's cursor per segment. A wave that finds a cursor past
+					// the surface's last segment never returns to that surface
 					for (;;) {
-						if (stripe_open) {
-							uint32_t want = stripe_rem / kWfGuideDiv;   // guided: a share of what the stripe still holds, whole units, at most kWfGrab entries
-							want = want > kWfGrab ? kWfGrab : want;
-							want = want < kWfUnit ? kWfUnit : want / kWfUnit * kWfUnit;
-							uint32_t* sched = W.sched + (size_t)unit_surf * (kWfStripes + 1u) * kWfSchedStride;
-							uint32_t b = 0;
-							if (lane == 0) b = atomicAdd(sched + (size_t)(stripe_cur + 1u) * kWfSchedStride, want);
-							b = __builtin_amdgcn_readfirstlane(b);
-							if (stripe_lo + b < stripe_hi) {
-								grab_pos = stripe_lo + b;
-								grab_end = grab_pos + want < stripe_hi ? grab_pos + want : stripe_hi;
-								stripe_rem = stripe_hi - grab_end;
-								if (grab_end == stripe_hi) {   // this grab holds the stripe's last entry: exactly one wave gets here per stripe
-									stripe_open = false;
-									if (lane == 0) {
-										const uint32_t closed = atomicAdd(sched, 1u) + 1u;
-										if (closed == stripe_n) atomicOr(closed_mask, 1ull << unit_surf);
-									}
-								}
-								break;
-							}
-							stripe_open = false;   // others took the rest meanwhile
-						}
-						// another stripe of the current queue, else the next open queue in this XCD's order
-						if (unit_surf < 0 || queue_done) {
-							if (order_pos >= n_order) { more = false; break; }
-							const unsigned long long closed = __hip_atomic_load(closed_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						if (unit_surf < 0) {
 							int u = -1;
 							for (; order_pos < n_order; order_pos++) {
 								const int c = wf_surface_at(xcd, order_pos, n_surf);
-								if (c >= 0 && !((closed >> c) & 1ull) && W.ctr[kWfCtrLen + c] != 0) { u = c; break; }
+								if (c >= 0 && W.ctl[kWfCtlSeg + c] != 0) { u = c; break; }
 							}
 							u = __builtin_amdgcn_readfirstlane(u);
 							if (u < 0) { more = false; break; }
 							unit_surf = u;
-							queue_done = false;
 						}
-						const uint32_t len = __builtin_amdgcn_readfirstlane(W.ctr[kWfCtrLen + unit_surf]);
-						const uint32_t slen = ((len + kWfStripes * kWfUnit - 1u) / (kWfStripes * kWfUnit)) * kWfUnit;   // entries per stripe
-						stripe_n = (len + slen - 1u) / slen;
-						uint32_t* sched = W.sched + (size_t)unit_surf * (kWfStripes + 1u) * kWfSchedStride;
-						uint32_t taken = 0xFFFFFFFFu;   // lane c: what stripe c has handed out so far
-						if (lane < stripe_n) taken = __hip_atomic_load(sched + (size_t)(lane + 1u) * kWfSchedStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						const uint32_t my_len = lane < stripe_n ? ((lane + 1u) * slen < len ? slen : len - lane * slen) : 0u;
-						const uint64_t open_m = __ballot(lane < stripe_n && taken < my_len);
-						if (open_m == 0) { queue_done = true; order_pos++; continue; }
-						const uint32_t s0 = stripe0 % stripe_n;   // first open stripe at or after this wave's own one
-						const uint64_t hi_m = open_m >> s0;
-						stripe_cur = hi_m ? s0 + (uint32_t)__builtin_ctzll(hi_m) : (uint32_t)__builtin_ctzll(open_m);
-						stripe_lo = stripe_cur * slen;
-						stripe_hi = stripe_lo + slen < len ? stripe_lo + slen : len;
-						stripe_rem = stripe_hi - stripe_lo - __builtin_amdgcn_readlane(taken, stripe_cur);
-						stripe_open = true;
+						uint32_t k = 0;
+						if (lane == 0) k = atomicAdd(&W.ctl[kWfCtlCur + 64u * (uint32_t)unit_surf], 1u);
+						k = __builtin_amdgcn_readfirstlane(k);
+						if (k < W.ctl[kWfCtlSeg + unit_surf]) {
+							const uint2 sg = W.seg[(size_t)unit_surf * W.seg_cap + k];
+							seg_pos = __builtin_amdgcn_readfirstlane(sg.x);
+							seg_end = seg_pos + __builtin_amdgcn_readfirstlane(sg.y);
+							break;
+						}
+						unit_surf = -1;
+						order_pos++;
 					}
-				}
-				if (more) {
-					unit_pos = unit_base = grab_pos;
-					unit_end = grab_pos + kWfUnit < grab_end ? grab_pos + kWfUnit : grab_end;
-					grab_pos = unit_end;
 				}
 				if (more) {
 					WFPROF(5);
-					// stage the unit's pairs into this wave's LDS slice (coalesced queue read, near-sequential pair reads)
-					for (uint32_t j = lane; j < unit_end - unit_base; j += 64) {
-						const uint32_t p = W.queue[(size_t)unit_surf * W.queue_cap + unit_base + j];
-						s_pair[wave][j] = p;
-						s_ray[wave][j][0] = W.pair_ray[2 * (size_t)p];
-						s_ray[wave][j][1] = W.pair_ray[2 * (size_t)p + 1];
+					// stage the next <= 64 entries of the segment into this wave's LDS slice (coalesced: the entries are contiguous)
+					unit_n = seg_end - seg_pos < kWfUnit ? seg_end - seg_pos : kWfUnit;
+					unit_pos = 0;
+					if (lane < unit_n) {
+						const size_t e = (size_t)seg_pos + lane;
+						s_ray[wave][lane][0] = W.qent[2 * e];
+						s_ray[wave][lane][1] = W.qent[2 * e + 1];
 					}
+					seg_pos += unit_n;
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				}
@@ -335,16 +318,16 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 			}
 			if (more) {
 				WFT0();
-				const uint32_t avail = unit_end - unit_pos;
+				const uint32_t avail = unit_n - unit_pos;
 				const uint32_t r = rank_in(idle_m);
 				if (!busy && r < avail) {
 					WFPROF(4);
 #ifdef PTX_WF_PROF
 					walk_max = walk_steps > walk_max ? walk_steps : walk_max; walk_steps = 0;
 #endif
-					const uint32_t e = unit_pos - unit_base + r;
+					const uint32_t e = unit_pos + r;
 					const float4 e0 = s_ray[wave][e][0], e1 = s_ray[wave][e][1];
-					pair = s_pair[wave][e];
+					slot = __float_as_uint(e0.w);
 					o = mk(e0.x, e0.y, e0.z);
 					d = mk(e1.x, e1.y, e1.z);
 					const SurfaceRec& sf = S.surfaces[unit_surf];
@@ -354,7 +337,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 						busy = true; have = true;
 						node = sf.kd_root; min_dist = nr; max_dist = fr; fr0 = fr; sp = 0;
 					} else {
-						W.pair_hit[pair] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+						W.pair_hit[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
 					}
 				}
 				const uint32_t n_idle = (uint32_t)__popcll(idle_m);
@@ -372,7 +355,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 			if (busy) {
 				WFPROF(1);
 				if (!have) {
-					if (sp == 0) { W.pair_hit[pair] = make_float4(-1.0f, 0.f, 0.f, 0.f); busy = false; }
+					if (sp == 0) { W.pair_hit[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f); busy = false; }
 					else {
 						WFPROF(6);
 						sp--;
@@ -435,15 +418,15 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 				uint32_t best_tri = 0;
 				for (uint32_t k = 0; k < count; k++) {
 					WFPROF(3);
-					const uint32_t slot = g.leaf_ordered ? first_ref + k : g.refs[first_ref + k];
-					const float4 r0 = g.tris[3 * slot], r1 = g.tris[3 * slot + 1], r2 = g.tris[3 * slot + 2];
+					const uint32_t rslot = g.leaf_ordered ? first_ref + k : g.refs[first_ref + k];
+					const float4 r0 = g.tris[3 * rslot], r1 = g.tris[3 * rslot + 1], r2 = g.tris[3 * rslot + 2];
 					const uint32_t ti = __float_as_uint(r2.z);
 					float be, ga;
 					const float t = tri_test_pk(r0, r1, make_float2(r2.x, r2.y), pr, be, ga);
 					if (t >= 0 && t <= max_dist && (t < best_t || !(best_t >= 0))) { best_t = t; bb1 = be; bb2 = ga; best_tri = ti; }
 				}
 				if (best_t >= 0) {
-					W.pair_hit[pair] = make_float4(best_t, __uint_as_float(best_tri), bb1, bb2);
+					W.pair_hit[slot] = make_float4(best_t, __uint_as_float(best_tri), bb1, bb2);
 					busy = false;
 				}
 			}
@@ -452,16 +435,16 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 	}
 #ifdef PTX_WF_PROF
 	for (int k = 0; k < 8; k++) {
-		if (pt[k]) atomicAdd(&W.ctr[kWfCtrProf + 2 * k], pt[k]);
-		if (pl[k]) atomicAdd(&W.ctr[kWfCtrProf + 2 * k + 1], pl[k]);
+		if (pt[k]) atomicAdd(&W.ctl[kWfCtlProf + 2 * k], pt[k]);
+		if (pl[k]) atomicAdd(&W.ctl[kWfCtlProf + 2 * k + 1], pl[k]);
 	}
 	tc[0] = __builtin_amdgcn_s_memtime() - t_start;
-	if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&W.ctr[kWfCtrProf + 16 + k], (uint32_t)(tc[k] >> 10));
+	if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&W.ctl[kWfCtlProf + 16 + k], (uint32_t)(tc[k] >> 10));
 	// the slowest wave: its clock, its trips (node steps + triangle tests, wave level) and the most trips any single lane-walk took
-	if (lane == 0) { atomicMax(&W.ctr[kWfCtrProf + 24], (uint32_t)(tc[0] >> 10)); atomicMax(&W.ctr[kWfCtrProf + 25], pt[2] + pt[3]); }
-	atomicMax(&W.ctr[kWfCtrProf + 26], walk_steps > walk_max ? walk_steps : walk_max);
-	// when the waves ended, in eighths of ... the clock of the wave itself, binned by log2 of kilocycles (ctr[128 .. 159]: free in these builds)
-	if (lane == 0) { const uint32_t kc = (uint32_t)(tc[0] >> 10); atomicAdd(&W.ctr[128 + (kc ? 31 - __builtin_clz(kc) : 0)], 1u); if (pt[1] == 0) atomicAdd(&W.ctr[128 + 31], 1u); }
+	if (lane == 0) { atomicMax(&W.ctl[kWfCtlProf + 24], (uint32_t)(tc[0] >> 10)); atomicMax(&W.ctl[kWfCtlProf + 25], pt[2] + pt[3]); }
+	atomicMax(&W.ctl[kWfCtlProf + 26], walk_steps > walk_max ? walk_steps : walk_max);
+	// when the waves ended: their own clock binned by log2 of kilocycles (ctl[kWfCtlProf + 32 .. + 63])
+	if (lane == 0) { const uint32_t kc = (uint32_t)(tc[0] >> 10); atomicAdd(&W.ctl[kWfCtlProf + 32 + (kc ? 31 - __builtin_clz(kc) : 0)], 1u); if (pt[1] == 0) atomicAdd(&W.ctl[kWfCtlProf + 32 + 31], 1u); }
 #endif
 }
 
@@ -523,17 +506,19 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_merge_batch(DevScene S0, Inters
 DEV uint32_t wf_id(float4 q0) { return __float_as_uint(q0.w) & kWfIdMask; }
 DEV uint32_t wf_flags(float4 q0) { return __float_as_uint(q0.w) & ~kWfIdMask; }
 
-// ray t of a step: t < n_in: the extend ray of entry t (entries that wait for a shadow answer have none); else the shadow ray of entry t - n_in
+// ray t of a step with n_in entries: t < n_in: the extend ray of entry t (entries that wait for a shadow answer have none); else the
+// shadow ray of entry t - n_in
 struct StreamRays {
 	const float4* q;   // [4][cap]
 	const float4* r;   // [3][cap]
-	uint32_t cap, n_in;
-	DEV bool valid(uint32_t t) const {
+	uint32_t cap;
+	DEV uint32_t count(uint32_t n_in) const { return 2u * n_in; }
+	DEV bool valid(uint32_t t, uint32_t n_in) const {
 		const uint32_t i = t < n_in ? t : t - n_in;
 		const uint32_t f = wf_flags(q[i]);
 		return t < n_in ? !(f & (kWfZombie | kWfPending)) : (f & kWfRequest) != 0;
 	}
-	DEV void load(uint32_t t, V3& o, V3& d) const {
+	DEV void load(uint32_t t, uint32_t n_in, V3& o, V3& d) const {
 		if (t < n_in) { const float4 a = q[t], b = q[cap + t]; o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); }
 		else { const uint32_t i = t - n_in; const float4 a = r[i], b = r[cap + i]; o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); }
 	}
@@ -585,13 +570,19 @@ DEV bool wf_any(const DevScene& S, const WfBuffers& W, uint32_t i, V3 o, V3 d) {
 // shadow request: the sun's contribution, or the fate of a shadow catcher) and in its SHADE sweep of this one (shade_vertex), with
 // the survivors appended to the other stream buffer. 256-thread workgroups: no 128-register cap, nothing spills.
 template <bool SUN, bool ALPHA, bool TEX, bool WORKER>
-__global__ void __launch_bounds__(kWfBlock) k_wf_shade(DevScene S0, RenderParams P, WfBuffers W, WfStream in, WfStream out, uint32_t cap, uint32_t n_in, uint32_t slab_first,
+__global__ void __launch_bounds__(kWfBlock) k_wf_shade(DevScene S0, RenderParams P, WfBuffers W, WfStream in, WfStream out, uint32_t cap, uint32_t slab_first,
                                                       uint32_t* __restrict__ n_out, float4* __restrict__ sample_rad, const ModelRec* __restrict__ t_models,
                                                       const SurfaceRec* __restrict__ t_surfaces, const SpaceRec* __restrict__ t_spaces, const uint32_t* __restrict__ t_model_space) {
 	DevScene S = S0;
 	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;
+	if (W.ctl[1]) return;   // this step's pairs did not fit the pool: nothing is emitted, the later steps of the slab find no entries
 	__shared__ uint32_t s_wave_n[kWfBlock / 64];
 	const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+	// the grid covers the most entries the step can have; the entry count itself is only known on the device, and the workgroups
+	// beyond it leave at once (a loop over tiles in persistent workgroups keeps the scene tables live across iterations: 99-171 VGPRs
+	// instead of 83-123)
+	const uint32_t n_in = *W.n_in;
+	if ((uint64_t)blockIdx.x * kWfBlock >= (uint64_t)n_in) return;
 	const uint32_t i = blockIdx.x * kWfBlock + threadIdx.x;
 	V3 o = {0, 0, 0}, d = {0, 0, 1}, T = {1, 1, 1}, L = {0, 0, 0};
 	uint32_t id = 0, depth = 0, pass = 0, out_flags = 0;
@@ -637,7 +628,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_shade(DevScene S0, RenderParams
 			}
 		}
 	}
-	// survivors -> the other buffer: wave ballot + prefix, one counter fetch per workgroup
+	// survivors -> the other buffer: wave ballot + prefix, one counter fetch per tile
 	const uint64_t em = __ballot(emit);
 	if (lane == 0) s_wave_n[wave] = (uint32_t)__popcll(em);
 	__syncthreads();
@@ -661,16 +652,15 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_shade(DevScene S0, RenderParams
 }
 
 // ------------------------------------------------------------------------------------ launchers
+static int wf_classify_grid(int n_cu) { return n_cu * 2; }   // persistent 1024-thread workgroups (38 VGPRs: two per CU)
+
+// One slice of a batch: W.ctl must be zeroed, W.n_in == nullptr (the slice's ray count is known to the host)
 hipError_t launch_wf_intersect(const DevScene& S, const IntersectArgs& A, size_t first_ray, uint32_t n, const WfBuffers& W, int n_cu, hipStream_t stream) {
 	const SoaRays src{A.ox + first_ray, A.oy + first_ray, A.oz + first_ray, A.dx + first_ray, A.dy + first_ray, A.dz + first_ray};
-	const dim3 grid((n + kWfBlock - 1) / kWfBlock), block(kWfBlock);
-	hipError_t e = hipMemsetAsync(W.ctr, 0, kWfCtrBytes, stream);
-	if (e != hipSuccess) return e;
-	e = hipMemsetAsync(W.sched, 0, wf_sched_bytes(S.n_surfaces), stream);
-	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k_wf_classify<SoaRays>, dim3((n + kWfClassifyBlock - 1) / kWfClassifyBlock), dim3(kWfClassifyBlock), 0, stream, S, src, n, W, S.models, S.surfaces, S.spaces, S.model_space);
-	hipLaunchKernelGGL(k_wf_traverse, dim3(wf_traverse_grid(n_cu)), block, 0, stream, S, W, S.surfaces);
-	hipLaunchKernelGGL(k_wf_merge_batch, grid, block, 0, stream, S, A, first_ray, n, W, S.models, S.surfaces, S.spaces, S.model_space);
+	const int tiles = (int)((n + kWfTile - 1) / kWfTile);
+	hipLaunchKernelGGL(k_wf_classify<SoaRays>, dim3(tiles < wf_classify_grid(n_cu) ? tiles : wf_classify_grid(n_cu)), dim3(kWfClassifyBlock), 0, stream, S, src, n, W, S.models, S.surfaces, S.spaces, S.model_space);
+	hipLaunchKernelGGL(k_wf_traverse, dim3(wf_traverse_grid(n_cu)), dim3(kWfBlock), 0, stream, S, W, S.surfaces);
+	hipLaunchKernelGGL(k_wf_merge_batch, dim3((n + kWfBlock - 1) / kWfBlock), dim3(kWfBlock), 0, stream, S, A, first_ray, n, W, S.models, S.surfaces, S.spaces, S.model_space);
 	return hipGetLastError();
 }
 
@@ -680,32 +670,34 @@ hipError_t launch_wf_generate(const DevScene& S, const RenderParams& P, const Wf
 }
 
 template <bool SUN, bool ALPHA, bool TEX, bool WORKER>
-static void launch_shade_variant(const DevScene& S, const RenderParams& P, const WfBuffers& W, const WfStream& in, const WfStream& out, uint32_t cap, uint32_t n_in,
+static void launch_shade_variant(const DevScene& S, const RenderParams& P, const WfBuffers& W, const WfStream& in, const WfStream& out, uint32_t cap, uint32_t max_in,
                                  uint32_t slab_first, uint32_t* n_out, float4* sample_rad, hipStream_t stream) {
-	hipLaunchKernelGGL((k_wf_shade<SUN, ALPHA, TEX, WORKER>), dim3((n_in + kWfBlock - 1) / kWfBlock), dim3(kWfBlock), 0, stream, S, P, W, in, out, cap, n_in, slab_first, n_out,
-	                   sample_rad, S.models, S.surfaces, S.spaces, S.model_space);
+	hipLaunchKernelGGL((k_wf_shade<SUN, ALPHA, TEX, WORKER>), dim3((max_in + kWfBlock - 1) / kWfBlock), dim3(kWfBlock), 0, stream, S, P, W, in, out, cap,
+	                   slab_first, n_out, sample_rad, S.models, S.surfaces, S.spaces, S.model_space);
 }
 
-// One step of a slab: rays of the `n_in` entries of `in` (extend + shadow) through the queues, then one vertex per path into `out`;
-// *n_out (device) receives the number of entries written. Kernel variants as in the fused integrator (launch_pass_mode).
-hipError_t launch_wf_step(const DevScene& S, const RenderParams& P, const WfBuffers& W, const WfStream& in, const WfStream& out, uint32_t cap, uint32_t n_in,
-                          uint32_t slab_first, uint32_t* n_out, float4* sample_rad, int n_cu, hipStream_t stream) {
-	hipError_t e = hipMemsetAsync(W.ctr, 0, kWfCtrBytes, stream);
-	if (e != hipSuccess) return e;
-	if ((e = hipMemsetAsync(W.sched, 0, wf_sched_bytes(S.n_surfaces), stream)) != hipSuccess) return e;
-	if ((e = hipMemsetAsync(n_out, 0, 4, stream)) != hipSuccess) return e;
-	const StreamRays src{in.q, in.r, cap, n_in};
-	const uint32_t n_rays = 2u * n_in;
-	hipLaunchKernelGGL(k_wf_classify<StreamRays>, dim3((n_rays + kWfClassifyBlock - 1) / kWfClassifyBlock), dim3(kWfClassifyBlock), 0, stream, S, src, n_rays, W, S.models, S.surfaces,
+// One step of a slab: the rays of the *W.n_in entries of `in` (extend + shadow) through the queues, then one vertex per path into `out`;
+// the number of entries written is ADDED to *n_out (device, zero before the step). Nothing here depends on the entry count, which
+// only the device knows (`max_in` bounds it for the grids): the host enqueues the steps of a slab back to back.
+// Kernel variants as in the fused integrator (launch_pass_mode).
+hipError_t launch_wf_step(const DevScene& S, const RenderParams& P, const WfBuffers& W, const WfStream& in, const WfStream& out, uint32_t cap, uint32_t max_in,
+                          uint32_t slab_first, uint32_t* n_out, float4* sample_rad, int n_cu, hipStream_t stream, hipEvent_t* ev) {
+	const StreamRays src{in.q, in.r, cap};
+	const int tiles = (int)((2ull * max_in + kWfTile - 1) / kWfTile);
+	if (ev) (void)hipEventRecord(ev[0], stream);
+	hipLaunchKernelGGL(k_wf_classify<StreamRays>, dim3(tiles < wf_classify_grid(n_cu) ? tiles : wf_classify_grid(n_cu)), dim3(kWfClassifyBlock), 0, stream, S, src, 0u, W, S.models, S.surfaces,
 	                   S.spaces, S.model_space);
+	if (ev) (void)hipEventRecord(ev[1], stream);
 	hipLaunchKernelGGL(k_wf_traverse, dim3(wf_traverse_grid(n_cu)), dim3(kWfBlock), 0, stream, S, W, S.surfaces);
+	if (ev) (void)hipEventRecord(ev[2], stream);
 	const bool sun = S.sun.present != 0, alpha = S.any_alpha != 0;
-#define WF_SHADE(SUN_, ALPHA_, TEX_, WORKER_) launch_shade_variant<SUN_, ALPHA_, TEX_, WORKER_>(S, P, W, in, out, cap, n_in, slab_first, n_out, sample_rad, stream)
+#define WF_SHADE(SUN_, ALPHA_, TEX_, WORKER_) launch_shade_variant<SUN_, ALPHA_, TEX_, WORKER_>(S, P, W, in, out, cap, max_in, slab_first, n_out, sample_rad, stream)
 	if (P.integrator == 1u) { if (S.any_texture) WF_SHADE(true, true, true, true); else WF_SHADE(true, true, false, true); }
 	else if (S.any_texture) WF_SHADE(true, true, true, false);
 	else if (sun) { if (alpha) WF_SHADE(true, true, false, false); else WF_SHADE(true, false, false, false); }
 	else { if (alpha) WF_SHADE(false, true, false, false); else WF_SHADE(false, false, false, false); }
 #undef WF_SHADE
+	if (ev) (void)hipEventRecord(ev[3], stream);
 	return hipGetLastError();
 }
 

@@ -192,6 +192,25 @@ typedef struct ptx_render_stats {
 /* accum_rgba: device or host pointer. stats may be NULL (no device->host sync is then forced). */
 int ptx_render(ptx_scene* scene, const ptx_render_cfg* cfg, float* accum_rgba, ptx_render_stats* stats);
 
+/* Measurement aid (no counterpart in the reference): where the time of the last ptx_render that was given a stats pointer went.
+ * Scenes whose geometry fits the LDS or whose models have few surfaces run ONE fused kernel per pass (pipeline 0: fused_ms);
+ * many-surface scenes in global memory run the queue-based pipeline (pipeline 1) — per step of a slab of paths a classify, a
+ * traverse and a shade kernel. Their HIP-event times are collected only after ptx_ctx_set_timing(ctx, 1) (four event records per
+ * step); the workspace figures are always filled. */
+typedef struct ptx_kernel_timing {
+	uint32_t pipeline;          /* 0 = fused kernel, 1 = queue-based pipeline */
+	uint32_t steps;             /* queue-based pipeline: steps timed (classify + traverse + shade each) */
+	double classify_ms, traverse_ms, shade_ms;   /* sums over those steps */
+	double fused_ms;            /* fused kernel: sum over its launches */
+	uint32_t fused_launches, reserved;
+	uint64_t pool_pairs;        /* queue-based pipeline: pairs (ray, entered surface) the pool holds, 48 bytes each */
+	uint64_t peak_pairs;        /* ... the most pairs one step of one slab asked for */
+	uint64_t slab_paths;        /* ... camera paths per slab */
+	uint64_t workspace_bytes;   /* device memory the pipeline that ran holds on the context (streams, pool, queues) */
+} ptx_kernel_timing;
+int ptx_ctx_set_timing(ptx_ctx* ctx, int on);
+int ptx_ctx_get_timing(ptx_ctx* ctx, ptx_kernel_timing* out);
+
 /* Batch form of renderer::intersect (renderer.cpp:645-725) / distributed_scene::intersect
  * (src/scene/scene.hpp:20-21): the unit the host's INTERSECT stage queue would call.
  * Rays are SoA; directions are used as given (the reference normalises on construction, ray.cpp:6-8,
@@ -209,6 +228,11 @@ typedef struct ptx_hits {
 	float *u, *v;                   /* interpolated tex_coord (may be NULL) */
 } ptx_hits;
 int ptx_intersect_batch(ptx_scene* scene, const ptx_rays* rays, size_t n, const ptx_hits* hits);
+
+/* Batch form of scene::camera::get_ray(ndc, ratio) (LIB/scene/camera.cpp:10-21): what the integrator kernels compute for every camera
+ * sample after the pixel jitter (renderer.cpp:359-370), evaluated by the same device function.
+ * in [n][3]: ndc.x, ndc.y, aspect ratio;  out [n][6]: ray origin(3), direction(3). Pointers device or host (both of one kind). */
+int ptx_camera_rays_batch(ptx_scene* scene, const float* ndc_ratio, size_t n, float* rays);
 
 /* Batch form of the SHADING stage's sampling functions — core::pbr::importance_diffuse / importance_specular / pdf_diffuse /
  * pdf_specular / fresnel (LIB/core/pbr.cpp:71-184), util::rand_cone_vec (LIB/util/rand_cone_vec.cpp:8-35) and core::reflect
