@@ -43,7 +43,8 @@ struct DevScene {
 	const uint2* nodes;      // KD nodes of all surfaces (global-memory traversal)
 	const uint32_t* refs;    // unused by the kernels since the global path reads leaf-ordered records; kept for ptx_scene_get_array parity
 	const float4* tris;   // 3 per triangle: corners + vertex ids (TriRec)
-	const float4* tri_isect; // global-memory traversal: one TriIsect per leaf reference, in leaf order, triangle id in word 10
+	const float4* tri_isect; // global-memory traversal: one TriIsect per leaf reference, in leaf order, triangle id in word 10; same allocation as `nodes`, behind them
+	uint64_t geom_bytes;     // bytes of that allocation (nodes + records)
 	// resident copy (staged into LDS by MODE_LDS / MODE_HYBRID kernels): nodes, refs and one TriIsect per triangle of the
 	// surfaces that fit, indices rewritten to be local to these arrays (SurfaceRec::lds_root)
 	const uint2* res_nodes;

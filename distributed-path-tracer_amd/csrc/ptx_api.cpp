@@ -149,25 +149,35 @@ int upload_scene(ptx_scene* sc) {
 	};
 	HIP_TRY(up(sc->d_models, h.models.data(), h.models.size() * sizeof(ModelRec), h.models.size() * sizeof(ModelRec)));
 	HIP_TRY(up(sc->d_materials, h.materials.data(), h.materials.size() * sizeof(MaterialRec), h.materials.size() * sizeof(MaterialRec)));
-	HIP_TRY(up(sc->d_nodes, h.kd_nodes.data(), h.kd_nodes.size() * 8, pad16(h.kd_nodes.size() * 8) + 16));   // + 16: the child-pair fetch of the last branch may read one node past the end
 	HIP_TRY(up(sc->d_refs, h.kd_refs.data(), h.kd_refs.size() * 4, pad16(h.kd_refs.size() * 4)));
 	HIP_TRY(up(sc->d_tris, h.tris.data(), h.tris.size() * 48, h.tris.size() * 48));
 	decide_mode(sc);   // sets SurfaceRec::lds_root: before the surface table goes up
 	HIP_TRY(up(sc->d_surfaces, h.surfaces.data(), h.surfaces.size() * sizeof(SurfaceRec), h.surfaces.size() * sizeof(SurfaceRec)));
+	// KD nodes and the global-memory triangle records share ONE allocation: the queue-based traverse kernel addresses both as
+	// `base + 32-bit offset` (wavefront.hip). + 16: the child-pair fetch of the last branch may read one node past the end.
+	const size_t nodes_bytes = (pad16(h.kd_nodes.size() * 8) + 16 + 255) & ~(size_t)255;
+	size_t isect_bytes = 0;
+	std::vector<TriIsect> leaf;
 	if (sc->mode != MODE_LDS) {
 		if (sc->leaf_ordered) {
 			// surfaces that stay in L2/HBM: one record per leaf reference, in leaf order, so that a leaf's triangles are one
 			// contiguous run and the reference -> record indirection is gone (Geom::leaf_ordered)
-			std::vector<TriIsect> leaf(h.kd_refs.size());
+			leaf.resize(h.kd_refs.size());
 			for (size_t r = 0; r < leaf.size(); r++) leaf[r] = h.tri_isect[h.kd_refs[r]];
-			HIP_TRY(up(sc->d_isect, leaf.data(), leaf.size() * 48, leaf.size() * 48));
-			HIP_TRY(hipStreamSynchronize(c->stream));   // `leaf` is about to go out of scope
+			isect_bytes = leaf.size() * 48;
 		} else {
 			// one record per TRIANGLE, reached through the leaf references: an extra dependent fetch per test, but a working set
 			// (nodes + refs + records) several times smaller when leaves share many triangles
-			HIP_TRY(up(sc->d_isect, h.tri_isect.data(), h.tri_isect.size() * 48, h.tri_isect.size() * 48));
+			isect_bytes = h.tri_isect.size() * 48;
 		}
 	}
+	HIP_TRY(sc->d_nodes.ensure(nodes_bytes + std::max<size_t>(isect_bytes, 16)));
+	HIP_TRY(hipMemsetAsync(sc->d_nodes.p, 0, nodes_bytes + std::max<size_t>(isect_bytes, 16), c->stream));
+	if (!h.kd_nodes.empty()) HIP_TRY(hipMemcpyAsync(sc->d_nodes.p, h.kd_nodes.data(), h.kd_nodes.size() * 8, hipMemcpyHostToDevice, c->stream));
+	if (isect_bytes)
+		HIP_TRY(hipMemcpyAsync((char*)sc->d_nodes.p + nodes_bytes, sc->leaf_ordered ? (const void*)leaf.data() : (const void*)h.tri_isect.data(), isect_bytes, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));   // `leaf` is a local
+	std::vector<TriIsect>().swap(leaf);
 	if (sc->mode != MODE_GLOBAL) {
 		HIP_TRY(up(sc->d_res_nodes, h.res_nodes.data(), h.res_nodes.size() * 8, pad16(h.res_nodes.size() * 8)));
 		HIP_TRY(up(sc->d_res_refs, h.res_refs.data(), h.res_refs.size() * 4, pad16(h.res_refs.size() * 4)));
@@ -194,7 +204,8 @@ int upload_scene(ptx_scene* sc) {
 	d.refs = (const uint32_t*)sc->d_refs.p;
 	d.tris = (const float4*)sc->d_tris.p;
 	d.vattr = (const float4*)sc->d_vattr.p;
-	d.tri_isect = (const float4*)sc->d_isect.p;
+	d.tri_isect = isect_bytes ? (const float4*)((const char*)sc->d_nodes.p + nodes_bytes) : nullptr;
+	d.geom_bytes = (uint64_t)nodes_bytes + isect_bytes;
 	d.res_nodes = (const uint2*)sc->d_res_nodes.p;
 	d.res_refs = (const uint32_t*)sc->d_res_refs.p;
 	d.res_tris = (const float4*)sc->d_res_tris.p;
@@ -534,7 +545,11 @@ namespace {
 // Pair space is a pool sized from DEMAND: `wf_pairs_per_ray` of the scene (what its rays were seen to need; before the first
 // measurement min(surfaces, 4)) plus a margin decides how many rays a pool of `pool_pairs` serves; a step that needs more raises the
 // overflow word and the slab / slice is repeated in smaller pieces with the ratio it reported.
-constexpr uint64_t kWfPoolPairs = 128ull << 20;   // pairs of a render's pool (48 B each: 6 GB) — 16 M-path slabs on the 24-surface atrium (3.2 pairs per ray, two rays per path and step)
+// pairs of a render's pool, 48 B each. Measured on the 24-surface atrium (3.2 pairs per ray, two rays per path and step; 1080p, 64 spp,
+// profiles/round3_wf_ab.txt): 128 Mi pairs (6 GB: 17 M-path slabs, 10 GB of workspace in all) 409 Msamples/s, 256 Mi 435, 384 Mi 447,
+// 512 Mi 452 — every step of a slab ends with a few waves finishing walks of hundreds of dependent fetches, and a larger slab has
+// fewer such ends per path. The default takes 384 Mi (18 GB of a 288 GB device) unless that is more than a sixth of the free memory.
+constexpr uint64_t kWfPoolPairs = 384ull << 20;
 constexpr uint64_t kWfBatchPairs = 32ull << 20;   // ... of a batch-intersect slice
 constexpr uint32_t kWfFlowWords = 64, kWfFlowRays = 58 /* 64-bit */, kWfFlowPeak = 60, kWfFlowOverflow = 63, kWfMaxRound = 56;   // flow words: [s] entries of step s of the round, then the pool's peak demand and the overflow word
 bool use_wavefront(const ptx_scene* sc) {
@@ -566,7 +581,7 @@ hipError_t wf_workspace(ptx_ctx* c, int set, size_t rays, size_t pool, size_t n_
 	if ((e = w.ctl.ensure(steps * kWfCtlWords * 4)) != hipSuccess) return e;
 	if ((e = w.flow.ensure(kWfFlowWords * 4)) != hipSuccess) return e;
 	if (!w.flow_host && (e = hipHostMalloc((void**)&w.flow_host, kWfFlowWords * 4)) != hipSuccess) return e;
-	if ((e = w.spill.ensure((size_t)wf_traverse_grid(c->n_cu) * 4 * (size_t)kSpillWords * sizeof(uint2))) != hipSuccess) return e;
+	if ((e = w.spill.ensure((size_t)wf_traverse_grid(c->n_cu) * 4 * (size_t)kSpillWords * sizeof(uint4))) != hipSuccess) return e;   // 16-byte entries: node content + entry distance
 	W.qent = (float4*)w.qent.p; W.pair_hit = (float4*)w.pair_hit.p;
 	W.pool_cap = (uint32_t)std::min<size_t>(pool, 0xFFFFFFFFu);
 	W.seg = (uint2*)w.seg.p; W.seg_cap = (uint32_t)tiles;
@@ -605,23 +620,43 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 	if (stats) *stats = ptx_render_stats{};
 	if (cfg->spp == 0) return PTX_OK;
 
-	// Interleaved tile sharding: the pixels of this shard, tile by tile (rows inside a tile), as indices into the rectangle
+	// The order in which a pass enumerates its pixels (path id -> pixel). Per-sample radiance is keyed by (pixel, sample), so the order
+	// changes no result — only which rays sit next to each other in a wave and in a classify tile. "tiled": 8 x 8 pixel blocks (one
+	// wave of camera rays) inside 32 x 32 blocks (one classify tile) — coherent rays enter the same surfaces and walk the same nodes;
+	// PTX_PIXEL_ORDER=linear|tiled overrides (measurement). Interleaved tile sharding: only the pixels of this shard's image tiles.
 	uint64_t n_pixels = rect_pixels;
 	const uint32_t* d_pixels = nullptr;
-	if (sharded) {
-		const uint32_t ts = cfg->shard_tile ? cfg->shard_tile : 64u;
-		const uint32_t key[9] = {cfg->W, cfg->H, x0, y0, w, h, cfg->shard_index, cfg->shard_count, ts};
+	bool tiled = use_wavefront(sc);   // measured: profiles/round3_pixel_order.txt
+	if (const char* e = getenv("PTX_PIXEL_ORDER")) tiled = e[0] == 't';
+	if (sharded || tiled) {
+		const uint32_t ts = sharded ? (cfg->shard_tile ? cfg->shard_tile : 64u) : 0u;
+		const uint32_t key[9] = {cfg->W, cfg->H, x0, y0, w, h, sharded ? cfg->shard_index : 0u, (sharded ? cfg->shard_count : 1u) | (tiled ? 0x80000000u : 0u), ts};
 		if (memcmp(key, c->list_key, sizeof key) != 0 || !c->pixel_list.p) {
 			std::vector<uint32_t> list;
-			const uint32_t tiles_x = (cfg->W + ts - 1) / ts;
-			for (uint32_t ty = y0 / ts; ty <= (y0 + h - 1) / ts; ty++)
-				for (uint32_t tx = x0 / ts; tx <= (x0 + w - 1) / ts; tx++) {
-					if ((uint64_t)(ty * (uint64_t)tiles_x + tx) % cfg->shard_count != cfg->shard_index) continue;
-					const uint32_t ya = std::max(ty * ts, y0), yb = std::min((ty + 1) * ts, y0 + h);
-					const uint32_t xa = std::max(tx * ts, x0), xb = std::min((tx + 1) * ts, x0 + w);
+			// the pixels of the image rectangle [xa, xb) x [ya, yb): rows, or 8 x 8 blocks inside 32 x 32 blocks anchored at the image origin
+			auto add_rect = [&](uint32_t xa, uint32_t ya, uint32_t xb, uint32_t yb) {
+				if (!tiled) {
 					for (uint32_t y = ya; y < yb; y++)
 						for (uint32_t x = xa; x < xb; x++) list.push_back((y - y0) * w + (x - x0));
+					return;
 				}
+				for (uint32_t by = ya / 32; by <= (yb - 1) / 32; by++)
+					for (uint32_t bx = xa / 32; bx <= (xb - 1) / 32; bx++)
+						for (uint32_t sy = 0; sy < 4; sy++)
+							for (uint32_t sx = 0; sx < 4; sx++)
+								for (uint32_t y = by * 32 + sy * 8; y < by * 32 + sy * 8 + 8; y++)
+									for (uint32_t x = bx * 32 + sx * 8; x < bx * 32 + sx * 8 + 8; x++)
+										if (x >= xa && x < xb && y >= ya && y < yb) list.push_back((y - y0) * w + (x - x0));
+			};
+			if (!sharded) add_rect(x0, y0, x0 + w, y0 + h);
+			else {
+				const uint32_t tiles_x = (cfg->W + ts - 1) / ts;
+				for (uint32_t ty = y0 / ts; ty <= (y0 + h - 1) / ts; ty++)
+					for (uint32_t tx = x0 / ts; tx <= (x0 + w - 1) / ts; tx++) {
+						if ((uint64_t)(ty * (uint64_t)tiles_x + tx) % cfg->shard_count != cfg->shard_index) continue;
+						add_rect(std::max(tx * ts, x0), std::max(ty * ts, y0), std::min((tx + 1) * ts, x0 + w), std::min((ty + 1) * ts, y0 + h));
+					}
+			}
 			// a previous render with stats == NULL and a device buffer returns without a sync (ptx.h): its generate / resolve kernels may
 			// still be reading the list this call is about to replace, and the context's stream is non-blocking (not ordered with the
 			// NULL stream a plain hipMemcpy would use) — drain it first, then upload on the same stream
@@ -697,9 +732,18 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 	auto slab_cap = [&]() -> uint32_t {   // paths of a slab: the pool must hold the pairs of its busiest step
 		const double per_path = 2.0 * wf_ratio_guess(sc);
 		const uint64_t by_pool = (uint64_t)std::max(65536.0, (double)pool_pairs / per_path);
-		return (uint32_t)std::min<uint64_t>({(pass_paths + wf_sets - 1) / wf_sets, (uint64_t)kWfMaxSlab - 1, by_pool});
+		const uint64_t cap = std::min<uint64_t>({(pass_paths + wf_sets - 1) / wf_sets, (uint64_t)kWfMaxSlab - 1, by_pool});
+		const uint64_t n_slabs = (pass_paths + cap - 1) / cap;   // slabs of equal size rather than full ones and a remainder
+		return (uint32_t)((pass_paths + n_slabs - 1) / n_slabs);
 	};
 	if (wavefront) {
+		{
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+				const uint64_t held = c->wf[0].qent.cap + c->wf[0].pair_hit.cap;   // what the context already holds counts as available
+				pool_pairs = std::min<uint64_t>(pool_pairs, std::max<uint64_t>(16ull << 20, (free_b + held) / 6 / 48));
+			} else (void)hipGetLastError();
+		}
 		if (const char* e = getenv("PTX_WF_PAIRS_M")) pool_pairs = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;   // measurement: pool size in Mi pairs
 		pool_pairs = std::min<uint64_t>(pool_pairs, 0xFFFFFFFFull);
 		wf_sets = getenv("PTX_WF_TWO_STREAMS") ? 2 : 1;   // measurement: two slabs side by side on two streams

@@ -448,6 +448,222 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 #endif
 }
 
+// ------------------------------------------------------------------------------------ traverse, one loop
+// The same walks as k_wf_traverse, organised as ONE loop without inner loops: per trip every busy lane advances by one step of
+// core::mesh::intersect — a node step (mesh.cpp:327-370) when it stands on a branch, a triangle test (mesh.cpp:381-389) when it
+// stands in a leaf — and ALL the trip's fetches (the branch lanes' child pair, the leaf lanes' triangle record) are issued together
+// at the top, so that a trip waits for memory once. In the nested loops a wave made one dependent fetch per node trip and per
+// triangle trip, each at 22-38 % of the lanes (a lane that reached its leaf waited for the slowest descent, and the other way round):
+// 14-26 lane steps per pair took 17-33 M wave trips per 25 M pairs; here the lanes of a wave step together: the same steps in a
+// third of the trips. The pending-subtree stack keeps what the reference's stack keeps (mesh.cpp:317-325: node, min_dist, max_dist)
+// with the node's CONTENT (8 bytes) in place of its pointer — both children are in registers when one of them is set aside, and a
+// pop needs no fetch — as 16-byte entries in LDS (one ds_write_b128 / ds_read_b128; a register-held top would be rotated with a
+// dozen moves on every push and pop of any lane). The surface's root node is read once per staged unit (wave-uniform). Nodes and
+// triangle records live in ONE allocation (upload_scene): every fetch is `base + 32-bit offset`.
+#ifndef PTX_WF_LDS_STACK2
+#define PTX_WF_LDS_STACK2 4
+#endif
+constexpr int kWfLdsStack2 = PTX_WF_LDS_STACK2;
+constexpr int kWfMaxStack = kRegStack + kSpillStack;   // entries a walk may set aside (the nested kernels' bound: 27 > mesh.hpp:34's 25 levels)
+struct alignas(8) NodePair { uint32_t x, y, z, w; };   // two adjacent 8-byte nodes: 8-byte aligned, fetched as one 16-byte load
+
+__global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffers W, const SurfaceRec* __restrict__ t_surfaces) {
+	DevScene S = S0;
+	S.surfaces = t_surfaces;
+	if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(W.peak, W.ctl[0]);   // demand of this step (counted on even when it overflowed the pool)
+	if (W.ctl[1]) return;   // this step's pairs did not fit the pool: the host repeats the slab
+	__shared__ float4 s_ray[kWfBlock / 64][kWfUnit][2];
+	__shared__ uint4 s_stk[kWfLdsStack2 > 0 ? kWfLdsStack2 : 1][kWfBlock];
+	const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+	const uint32_t xcd = blockIdx.x & 7u;
+	// beyond the LDS levels: lane-interleaved rows in global memory
+	uint4* const spill4 = reinterpret_cast<uint4*>(W.spill) + (size_t)(blockIdx.x * (kWfBlock / 64) + wave) * (kSpillStack * 64) + lane;
+	const unsigned char* const geom = reinterpret_cast<const unsigned char*>(S.nodes);
+	const uint32_t tri_off = (uint32_t)(reinterpret_cast<const unsigned char*>(S.tri_isect) - geom);   // same allocation (upload_scene)
+	const uint32_t n_surf = S.n_surfaces;
+	const uint32_t n_order = ((n_surf + 7u) / 8u) * 8u;
+
+	// wave-uniform: the segment being handed out, the unit of it staged in LDS, the root node of the unit's surface
+	uint32_t seg_pos = 0, seg_end = 0, unit_pos = 0, unit_n = 0, order_pos = 0;
+	int unit_surf = -1;
+	bool more = true;
+	uint2 root_nd = make_uint2(0, 0);
+	// per lane: the walk in progress (core::mesh::intersect's locals)
+	bool busy = false;
+	uint2 nd = make_uint2(0, KD_LEAF);          // the node the lane stands on
+	uint32_t slot = 0, k = 0, best_tri = 0;
+	int sp = 0;
+	float min_dist = 0, max_dist = 0, best_t = -1.0f, bb1 = 0, bb2 = 0;
+	V3 o = {0, 0, 0}, d = {0, 0, 1};
+#ifdef PTX_WF_PROF
+	uint32_t pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pl[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 trips, 1 busy lanes, 2 node steps, 3 triangle tests, 4 hand-outs, 5 unit fetches, 6 pops
+	uint64_t tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	const uint64_t t_start = __builtin_amdgcn_s_memtime();
+	uint32_t walk_steps = 0, walk_max = 0;
+#endif
+
+	for (;;) {
+		WFPROF(0);
+		const uint64_t idle_m = __ballot(!busy);
+		if (more && ((uint32_t)__popcll(idle_m) >= kWfRefillMin || ~idle_m == 0)) {
+			if (unit_pos == unit_n) {
+				WFT0();
+				if (seg_pos == seg_end) {
+					for (;;) {   // next segment: this XCD's surfaces first; one atomic on the surface's cursor per segment
+						if (unit_surf < 0) {
+							int u = -1;
+							for (; order_pos < n_order; order_pos++) {
+								const int c = wf_surface_at(xcd, order_pos, n_surf);
+								if (c >= 0 && W.ctl[kWfCtlSeg + c] != 0) { u = c; break; }
+							}
+							u = __builtin_amdgcn_readfirstlane(u);
+							if (u < 0) { more = false; break; }
+							unit_surf = u;
+							const uint2 r = S.nodes[S.surfaces[u].kd_root];
+							root_nd = make_uint2(__builtin_amdgcn_readfirstlane(r.x), __builtin_amdgcn_readfirstlane(r.y));
+						}
+						uint32_t g = 0;
+						if (lane == 0) g = atomicAdd(&W.ctl[kWfCtlCur + 64u * (uint32_t)unit_surf], 1u);
+						g = __builtin_amdgcn_readfirstlane(g);
+						if (g < W.ctl[kWfCtlSeg + unit_surf]) {
+							const uint2 sg = W.seg[(size_t)unit_surf * W.seg_cap + g];
+							seg_pos = __builtin_amdgcn_readfirstlane(sg.x);
+							seg_end = seg_pos + __builtin_amdgcn_readfirstlane(sg.y);
+							break;
+						}
+						unit_surf = -1;
+						order_pos++;
+					}
+				}
+				if (more) {
+					WFPROF(5);
+					unit_n = seg_end - seg_pos < kWfUnit ? seg_end - seg_pos : kWfUnit;
+					unit_pos = 0;
+					if (lane < unit_n) {
+						const size_t e = (size_t)seg_pos + lane;
+						s_ray[wave][lane][0] = W.qent[2 * e];
+						s_ray[wave][lane][1] = W.qent[2 * e + 1];
+					}
+					seg_pos += unit_n;
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				}
+				WFT1(1);
+			}
+			if (more) {
+				WFT0();
+				const uint32_t avail = unit_n - unit_pos;
+				const uint32_t r = rank_in(idle_m);
+				if (!busy && r < avail) {
+					WFPROF(4);
+#ifdef PTX_WF_PROF
+					walk_max = walk_steps > walk_max ? walk_steps : walk_max; walk_steps = 0;
+#endif
+					const uint32_t e = unit_pos + r;
+					const float4 e0 = s_ray[wave][e][0], e1 = s_ray[wave][e][1];
+					slot = __float_as_uint(e0.w);
+					o = mk(e0.x, e0.y, e0.z);
+					d = mk(e1.x, e1.y, e1.z);
+					const SurfaceRec& sf = S.surfaces[unit_surf];
+					const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+					float nr, fr;
+					if (aabb_test_inv(sf.bmin, sf.bmax, o, inv, nr, fr)) {   // mesh.cpp:308-315 (the classification saw the same test pass)
+						busy = true;
+						nd = root_nd; min_dist = nr; max_dist = fr; sp = 0; k = 0; best_t = -1.0f;
+					} else {
+						W.pair_hit[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+					}
+				}
+				const uint32_t n_idle = (uint32_t)__popcll(idle_m);
+				unit_pos += n_idle < avail ? n_idle : avail;
+				WFT1(2);
+			}
+		}
+		if (__ballot(busy) == 0) {
+			if (!more) break;
+			continue;
+		}
+		if (busy) WFPROF(1);
+		// The trip itself is straight-line code under per-lane predicates: both kinds of step are computed by every lane and kept
+		// where they apply (selects). With branches around the two kinds, every state variable a kind updates was copied at every join
+		// (a third of the loop's vector instructions were moves) for nothing — a wave has lanes of both kinds in nearly every trip.
+		// ---- the trip's fetches: child pair (16 bytes) of a branch, the next triangle record (48 bytes) of a leaf
+		const bool leaf = (nd.y & 3u) == KD_LEAF;
+		const bool branch = busy && !leaf;
+		const uint32_t count = nd.y >> 2;   // of a leaf
+		const bool tri = busy && leaf && k < count;
+		// every lane fetches (no join, no copies): a lane with nothing to fetch reads the allocation's first 16 bytes
+		const uint32_t off = branch ? (nd.y >> 4) * 8u : (tri ? tri_off + (nd.x + k) * 48u : 0u);
+		const NodePair q0 = *reinterpret_cast<const NodePair*>(geom + off);
+		float4 r1, r2;
+		if (tri) { r1 = *reinterpret_cast<const float4*>(geom + off + 16u); r2 = *reinterpret_cast<const float4*>(geom + off + 32u); }
+		// ---- node step (mesh.cpp:327-370; see mesh_traverse)
+		if (branch) WFPROF(2);
+		const uint32_t axis = nd.y & 3u;
+		const uint2 kid0 = make_uint2(q0.x, q0.y), kid1 = make_uint2(q0.z, q0.w);
+		const float split = __uint_as_float(nd.x);
+		const float oa = sel3(o, axis), da = sel3(d, axis);
+		const float split_dist = (split - oa) / da;
+		const bool has_l = nd.y & 4u, has_r = nd.y & 8u;
+		const bool left_first = oa < split;
+		// children sit at li (left, or right when there is no left) and li + 1 (right when both exist): kid0 / kid1
+		const bool first_is_kid0 = left_first || !has_l, second_is_kid0 = !left_first || !has_l;
+		const bool has_first = left_first ? has_l : has_r, has_second = left_first ? has_r : has_l;
+		const bool outside = split_dist < 0 || split_dist > max_dist;           // only the near child (mesh.cpp:354-357)
+		const bool far_only = !outside && split_dist < min_dist;                 // only the far child (:358-361)
+		const bool both = branch && !outside && !far_only;                       // near child now, far child set aside (:362-369)
+		const bool push = both && has_second && sp < kWfMaxStack;
+		if (push) {
+			WFPROF(7);
+			const uint2 c = second_is_kid0 ? kid0 : kid1;
+			const uint4 ent = make_uint4(c.x, c.y, __float_as_uint(split_dist), __float_as_uint(max_dist));
+			if (sp < kWfLdsStack2) s_stk[sp][threadIdx.x] = ent; else spill4[(sp - kWfLdsStack2) * 64] = ent;
+		}
+		sp += push ? 1 : 0;
+		max_dist = both ? split_dist : max_dist;
+		const bool has_next = far_only ? has_second : has_first;
+		const bool descend = branch && has_next;
+		const uint2 next_nd = (far_only ? second_is_kid0 : first_is_kid0) ? kid0 : kid1;
+		// ---- triangle test: nearest triangle of the leaf with t <= max_dist; ties keep the first (mesh.cpp:381-389)
+		if (tri) WFPROF(3);
+		const PRay pr = pack_ray(o, d);
+		const float4 r0 = make_float4(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w));
+		float be, ga;
+		const float t = tri_test_pk(r0, r1, make_float2(r2.x, r2.y), pr, be, ga);
+		const bool better = tri && t >= 0 && t <= max_dist && (t < best_t || !(best_t >= 0));
+		best_t = better ? t : best_t; bb1 = better ? be : bb1; bb2 = better ? ga : bb2; best_tri = better ? __float_as_uint(r2.z) : best_tri;
+		const uint32_t k1 = k + 1u;
+		const bool leaf_done = tri && k1 == count;
+		const bool hit = leaf_done && best_t >= 0;
+		// ---- the walk ends with a hit, goes on to the next pending subtree (mesh.cpp:317-325), or ends with nothing
+		const bool need_pop = busy && ((branch && !has_next) || (leaf && !tri) || (leaf_done && !hit));   // `leaf && !tri`: an empty leaf (the builder makes none)
+		const bool miss = need_pop && sp == 0;
+		if (hit || miss) W.pair_hit[slot] = hit ? make_float4(best_t, __uint_as_float(best_tri), bb1, bb2) : make_float4(-1.0f, 0.f, 0.f, 0.f);
+		const bool pop = need_pop && sp > 0;
+		if (pop) WFPROF(6);
+		sp -= pop ? 1 : 0;
+		uint4 ent = s_stk[sp < kWfLdsStack2 ? sp : 0][threadIdx.x];       // read by every lane; kept by the popping ones
+		if (__ballot(pop && sp >= kWfLdsStack2) != 0) { if (pop && sp >= kWfLdsStack2) ent = spill4[(sp - kWfLdsStack2) * 64]; }
+		nd = pop ? make_uint2(ent.x, ent.y) : (descend ? next_nd : nd);
+		min_dist = pop ? __uint_as_float(ent.z) : min_dist;
+		max_dist = pop ? __uint_as_float(ent.w) : max_dist;
+		k = (pop || descend) ? 0u : (tri ? k1 : k);
+		best_t = (pop || descend) ? -1.0f : best_t;
+		busy = busy && !hit && !miss;
+	}
+#ifdef PTX_WF_PROF
+	for (int q = 0; q < 8; q++) {
+		if (pt[q]) atomicAdd(&W.ctl[kWfCtlProf + 2 * q], pt[q]);
+		if (pl[q]) atomicAdd(&W.ctl[kWfCtlProf + 2 * q + 1], pl[q]);
+	}
+	tc[0] = __builtin_amdgcn_s_memtime() - t_start;
+	if (lane == 0) for (int q = 0; q < 6; q++) atomicAdd(&W.ctl[kWfCtlProf + 16 + q], (uint32_t)(tc[q] >> 10));
+	if (lane == 0) { atomicMax(&W.ctl[kWfCtlProf + 24], (uint32_t)(tc[0] >> 10)); atomicMax(&W.ctl[kWfCtlProf + 25], pt[0]); }
+	atomicMax(&W.ctl[kWfCtlProf + 26], walk_steps > walk_max ? walk_steps : walk_max);
+	if (lane == 0) { const uint32_t kc = (uint32_t)(tc[0] >> 10); atomicAdd(&W.ctl[kWfCtlProf + 32 + (kc ? 31 - __builtin_clz(kc) : 0)], 1u); if (pt[1] == 0) atomicAdd(&W.ctl[kWfCtlProf + 32 + 31], 1u); }
+#endif
+}
+
 // ------------------------------------------------------------------------------------ merge
 // renderer::intersect (core/renderer.cpp:645-671) over scene::model::intersect (scene/model.cpp:20-72) with core::mesh::intersect
 // replaced by the lookup of the pair's result: the loops, comparisons and the local -> world distance are scene_traverse's.
@@ -654,12 +870,20 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_shade(DevScene S0, RenderParams
 // ------------------------------------------------------------------------------------ launchers
 static int wf_classify_grid(int n_cu) { return n_cu * 2; }   // persistent 1024-thread workgroups (38 VGPRs: two per CU)
 
+// PTX_WF_KERNEL=1 (measurement): the nested-loop form of the traverse kernel instead of the one-loop form
+static void launch_traverse(const DevScene& S, const WfBuffers& W, int n_cu, hipStream_t stream) {
+	static const bool nested = [] { const char* e = getenv("PTX_WF_KERNEL"); return e && e[0] == '1'; }();
+	// the one-loop kernel reads a leaf's records in place (leaf-ordered copy) at 32-bit offsets from the nodes
+	if (nested || !S.glb_leaf_ordered || S.geom_bytes > 0xFFFFFFFFull) hipLaunchKernelGGL(k_wf_traverse, dim3(wf_traverse_grid(n_cu)), dim3(kWfBlock), 0, stream, S, W, S.surfaces);
+	else hipLaunchKernelGGL(k_wf_traverse2, dim3(wf_traverse_grid(n_cu)), dim3(kWfBlock), 0, stream, S, W, S.surfaces);
+}
+
 // One slice of a batch: W.ctl must be zeroed, W.n_in == nullptr (the slice's ray count is known to the host)
 hipError_t launch_wf_intersect(const DevScene& S, const IntersectArgs& A, size_t first_ray, uint32_t n, const WfBuffers& W, int n_cu, hipStream_t stream) {
 	const SoaRays src{A.ox + first_ray, A.oy + first_ray, A.oz + first_ray, A.dx + first_ray, A.dy + first_ray, A.dz + first_ray};
 	const int tiles = (int)((n + kWfTile - 1) / kWfTile);
 	hipLaunchKernelGGL(k_wf_classify<SoaRays>, dim3(tiles < wf_classify_grid(n_cu) ? tiles : wf_classify_grid(n_cu)), dim3(kWfClassifyBlock), 0, stream, S, src, n, W, S.models, S.surfaces, S.spaces, S.model_space);
-	hipLaunchKernelGGL(k_wf_traverse, dim3(wf_traverse_grid(n_cu)), dim3(kWfBlock), 0, stream, S, W, S.surfaces);
+	launch_traverse(S, W, n_cu, stream);
 	hipLaunchKernelGGL(k_wf_merge_batch, dim3((n + kWfBlock - 1) / kWfBlock), dim3(kWfBlock), 0, stream, S, A, first_ray, n, W, S.models, S.surfaces, S.spaces, S.model_space);
 	return hipGetLastError();
 }
@@ -688,7 +912,7 @@ hipError_t launch_wf_step(const DevScene& S, const RenderParams& P, const WfBuff
 	hipLaunchKernelGGL(k_wf_classify<StreamRays>, dim3(tiles < wf_classify_grid(n_cu) ? tiles : wf_classify_grid(n_cu)), dim3(kWfClassifyBlock), 0, stream, S, src, 0u, W, S.models, S.surfaces,
 	                   S.spaces, S.model_space);
 	if (ev) (void)hipEventRecord(ev[1], stream);
-	hipLaunchKernelGGL(k_wf_traverse, dim3(wf_traverse_grid(n_cu)), dim3(kWfBlock), 0, stream, S, W, S.surfaces);
+	launch_traverse(S, W, n_cu, stream);
 	if (ev) (void)hipEventRecord(ev[2], stream);
 	const bool sun = S.sun.present != 0, alpha = S.any_alpha != 0;
 #define WF_SHADE(SUN_, ALPHA_, TEX_, WORKER_) launch_shade_variant<SUN_, ALPHA_, TEX_, WORKER_>(S, P, W, in, out, cap, max_in, slab_first, n_out, sample_rad, stream)

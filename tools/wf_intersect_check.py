@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser(); ap.add_argument("--detail", type=int, default=5)
 ap.add_argument("--scene", default="atrium"); ap.add_argument("--spp", type=int, default=4)
 ap.add_argument("--only-wavefront", action="store_true", help="skip the fused kernel (profiling runs)")
 ap.add_argument("--stride", type=int, default=1, help="use every stride-th ray (small launches)")
+ap.add_argument("--sort", default="none", help="order of the rays of a batch: none | octant (direction octant, stable) | cell (8x8x8 grid cell of the origin, then octant) — what ray coherence is worth")
 args = ap.parse_args()
 ptx = importlib.import_module("distributed-path-tracer_amd")
 proc = importlib.import_module("distributed-path-tracer_amd.procedural")
@@ -65,7 +66,21 @@ def compare(a, b):
 
 
 o, dd = orgs[::args.stride].contiguous(), dirs[::args.stride].contiguous()
+def reorder(o, d):
+    if args.sort == "none":
+        return o, d
+    octant = ((d[:, 0] < 0).long() << 2) | ((d[:, 1] < 0).long() << 1) | (d[:, 2] < 0).long()
+    key = octant
+    if args.sort == "cell":
+        lo, hi = o.min(0).values, o.max(0).values
+        c = ((o - lo) / (hi - lo + 1e-9) * 8).clamp(0, 7).long()
+        key = (((c[:, 0] << 6) | (c[:, 1] << 3) | c[:, 2]) << 3) | octant
+    idx = torch.sort(key, stable=True).indices
+    return o[idx].contiguous(), d[idx].contiguous()
+
+
 for generation in range(3):
+    o, dd = reorder(o, dd)
     got, t_w = intersect(o, dd, True)
     ref, t_f = (got, t_w) if args.only_wavefront else intersect(o, dd, False)
     n = o.shape[0]
