@@ -5,7 +5,7 @@ A "step" = one pass of the integrator over one batch of synthetic input: ONE fra
 (scenes/cornell-box, the reference's own asset) at 1920x1080, 256 spp, 8 bounces, entirely through the C ABI (ptx_render).
 The scene is resident in HBM before the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scene cornell|mesh|atrium|atrium4k|jack]
 
 N = 1: one process, one GPU. N > 1: one process per GPU over RCCL (torch.distributed "nccl"); when this script is started from a
 plain shell (no WORLD_SIZE) with --gpus N > 1 it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
@@ -15,10 +15,16 @@ Default for N > 1 is STRONG scaling: the same 256-spp frame, its 64x64 image til
 each rank traces a contiguous share of the sample indices of every pixel instead), then ONE RCCL sum-reduce of the float32
 accumulation buffer onto rank 0 inside the timed region. --weak: every rank traces 256 spp of its own (the frame gets N*256).
 
+--scene picks the frame that is timed (default: the Cornell frame of configs[1]); the other scene classes of BASELINE.json — the 82 k-triangle
+mesh (config 3), the 262 k-triangle 24-surface atrium at 1080p / 8 bounces (config 4) and at 4K / 16 bounces (config 5), stand-ins for
+the bunny and Sponza the reference does not ship — shard over N ranks the same way (interleaved tiles + one RCCL reduce).
+
 Prints ONE JSON line on rank 0 (bench contract): value = whole-job Msamples/s; plus
   roofline     — dominant kernel (k_render_pass), bound by the resource that limits it (VALU issue), with the HBM view beside it
   psnr_db      — GPU vs CPU oracle on a fixed 1080p tile at equal spp and RNG keys (outside the timed region)
-  cpu_baseline — the UNMODIFIED reference renderer (oracle/_ref/ref_harness) timed on this box's host cores, best of 3
+  cpu_baseline — the UNMODIFIED reference renderer (oracle/_ref/ref_harness) timed on this box's host cores: median of 5 runs at 2 spp
+  configs      — (N = 1, default scene) configs 3 / 4 / 5 and jack-of-blades rendered after the timed loop, outside it: Msamples/s, Mrays/s,
+                 dominant kernel, its launch time and roofline view (tools/bench_configs.py)
 """
 import argparse
 import glob
@@ -36,6 +42,12 @@ CORNELL = os.path.join(ROOT, "scenes", "cornell-box", "cornell.gltf")
 KERNEL_SRCS = [os.path.join(ROOT, "distributed-path-tracer_amd", "csrc", f) for f in ("kernels.hip", "device_core.hpp")]   # what k_render_pass is compiled from
 
 W, H, SPP, BOUNCES = 1920, 1080, 256, 8
+# --scene: (scene key of tools/bench_configs.py, W, H, bounces, default spp, BASELINE config it stands for)
+SCENES = {"cornell": ("cornell", 1920, 1080, 8, 256, "configs[1]"),
+          "mesh": ("mesh6", 1920, 1080, 8, 64, "configs[2] class: Cornell + 81 920-triangle mesh (stand-in geometry)"),
+          "atrium": ("atrium", 1920, 1080, 8, 64, "configs[3] class: 262 176 triangles in 24 surfaces (stand-in geometry)"),
+          "atrium4k": ("atrium", 3840, 2160, 16, 16, "configs[4] class: the same scene at 4K, 16 bounces (stand-in geometry)"),
+          "jack": ("jack", 1920, 1080, 8, 64, "the reference's textured asset")}
 # /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # HBM3E spec peak
 N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs
@@ -70,30 +82,38 @@ def kernel_profile():
 
 
 def cpu_baseline():
-    """Time the reference's own renderer::render on the host cores: 1080p, 8 bounces, 1 spp (6-9 s each), best of 3."""
+    """Time the reference's own renderer::render on the host cores: Cornell 1080p, 8 bounces, 2 spp (4.1 M camera paths, ~15 s each at
+    the reference's speed), 5 runs: the median is the value, min / max and every run are listed."""
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    spp, n_runs = 2, 5
+    W, H, BOUNCES = 1920, 1080, 8
     if os.path.exists(harness):
-        # the reference's thread pool stops scaling early (allocator / refcount contention, SURVEY §6): on the GPU box (16-core share
+        # the reference's thread pool stops scaling early (allocator / refcount contention, SURVEY section 6): on the GPU box (16-core share
         # per GPU) 16 threads is its best setting (8: 0.23, 16: 0.65, 32: 0.20, 64: 0.13 Msamples/s at 960x540), so that is what is timed
         threads = str(min(16, os.cpu_count() or 1))
         runs = []
-        for _ in range(3):
-            out = subprocess.run([harness, "render", CORNELL, str(W), str(H), "1", str(BOUNCES), threads],
-                                 capture_output=True, text=True, timeout=600)
+        t_all = time.time()
+        for _ in range(n_runs):
+            out = subprocess.run([harness, "render", CORNELL, str(W), str(H), str(spp), str(BOUNCES), threads],
+                                 capture_output=True, text=True, timeout=900)
             runs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]))
-        best = max(runs, key=lambda r: r["msamples_per_s"])
-        return {"value": round(best["msamples_per_s"], 4), "unit": "Msamples/s", "cores": best["threads"], "kind": "reference",
+            if time.time() - t_all > 150 and len(runs) >= 3:     # a slow host: three runs are enough to name a median
+                break
+        vals = sorted(r["msamples_per_s"] for r in runs)
+        med = vals[len(vals) // 2]
+        return {"value": round(med, 4), "unit": "Msamples/s", "cores": runs[0]["threads"], "host_cores": os.cpu_count(), "kind": "reference",
+                "stat": f"median of {len(runs)} runs", "min": round(vals[0], 4), "max": round(vals[-1], 4),
                 "runs": [round(r["msamples_per_s"], 4) for r in runs],
-                "sample": f"Cornell {W}x{H}, 1 spp, {BOUNCES} bounces (2.07 M camera paths), renderer::render of the unmodified "
-                          f"reference, best of 3 runs ({', '.join('%.1f s' % r['seconds'] for r in runs)})"}
+                "sample": f"Cornell {W}x{H}, {spp} spp, {BOUNCES} bounces ({W * H * spp / 1e6:.2f} M camera paths per run), renderer::render of the "
+                          f"unmodified reference on {runs[0]['threads']} threads ({', '.join('%.1f s' % r['seconds'] for r in runs)})"}
     # the compiled reference is absent: time the oracle (my CPU restatement) instead
     from oracle import pt_oracle as ora
     sc = ora.OracleScene(ora.load_gltf(CORNELL))
     t = time.time()
-    sc.render(ora.make_cfg(W, H, 1, BOUNCES), threads=0)
+    sc.render(ora.make_cfg(W, H, spp, BOUNCES), threads=0)
     dt = time.time() - t
-    return {"value": round(W * H / dt / 1e6, 4), "unit": "Msamples/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"Cornell {W}x{H}, 1 spp, {BOUNCES} bounces, oracle restatement, {dt:.1f} s"}
+    return {"value": round(W * H * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": os.cpu_count(), "host_cores": os.cpu_count(), "kind": "port",
+            "sample": f"Cornell {W}x{H}, {spp} spp, {BOUNCES} bounces, oracle restatement, {dt:.1f} s"}
 
 
 def psnr_vs_oracle(ptx, scene, ctx):
@@ -136,9 +156,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel of the frame (default: the BASELINE config)")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel of the frame (default: 256 for the Cornell frame of the BASELINE config, 16-64 for the others)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs 3 / 4 / 5 block after the timed loop")
+    ap.add_argument("--scene", choices=sorted(SCENES), default="cornell", help="the frame that is timed (default: BASELINE configs[1])")
     ap.add_argument("--shard", choices=("tiles", "samples"), default="tiles",
                     help="how ONE frame is split over N ranks: interleaved 64x64 image tiles (default; BASELINE.json: \"image tiles shard naturally "
                          "across the 8 GPUs\") or contiguous shares of the sample indices of every pixel")
@@ -174,10 +196,15 @@ def main():
 
     ptx = importlib.import_module("distributed-path-tracer_amd")
     mg = importlib.import_module("distributed-path-tracer_amd.multigpu")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs
     ctx = ptx.Context(local_rank)
-    scene = ptx.Scene.load_gltf(ctx, CORNELL)      # scene is uploaded to HBM here, outside the timed region
+    scene_key, W, H, BOUNCES, default_spp, stands_for = SCENES[args.scene]
+    scene_cache = {}
+    scene = bench_configs.build_scene(ptx, ctx, scene_key, scene_cache)[0]      # built and uploaded to HBM here, outside the timed region
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
-    spp = args.spp
+    spp = args.spp or default_spp
+    headline = args.scene == "cornell"
     mode = "weak" if args.weak else args.shard
 
     def step(collect):
@@ -208,6 +235,13 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     my_rays = float(sum(s["rays"] for s in stats))
+    my_kernel_ms = float(sum(s["kernel_ms"] for s in stats)) / max(args.steps, 1)     # this rank's integrator time per frame: the tile load balance
+    rank_kernel_ms = [my_kernel_ms]
+    if world > 1:
+        k = torch.zeros(world, dtype=torch.float64, device="cpu" if rehearsal else accum.device)
+        k[rank] = my_kernel_ms
+        dist.all_reduce(k, op=dist.ReduceOp.SUM)
+        rank_kernel_ms = [round(float(v), 3) for v in k.tolist()]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -224,16 +258,18 @@ def main():
         launches = sum(s["passes"] for s in stats)
         kernel_ms = sum(s["kernel_ms"] for s in stats) / max(launches, 1)     # average launch of k_render_pass on rank 0 (HIP events on the ctx stream)
         rays_per_launch = my_rays / max(launches, 1)
-        hit_frac = 0.866                                                      # fraction of Cornell rays that hit a surface (oracle counters)
-        prof = kernel_profile()
+        bray, bray_file = bench_configs.load_json("round*_bray.json")            # the oracle's per-scene counters
+        hit_frac = next((r["hit_fraction"] for r in (bray or {}).get("scenes", []) if r["scene"].startswith("cornell (")), 1.0)
+        prof = kernel_profile() if headline else None
         # --- binding resource: VALU issue. Peak = one wave64 VALU instruction per SIMD every 2 cycles (measured: v_add_f32 2.00 cycles per
         # instruction per SIMD at >= 2 waves per SIMD, profiles/round2_valu_issue.txt) at the clock the kernel held; achieved = the kernel's
         # wave64 VALU instructions per second (count per ray from the PMC profile x this run's rays / this run's kernel time).
-        roof = {"bound": "valu", "kernel": "k_render_pass<LDS>", "avg_launch_ms": round(kernel_ms, 4), "launches": launches,
+        roof = {"bound": "valu", "kernel": "k_render_pass<LDS>" if headline else "see the configs block of the default run (tools/bench_configs.py)",
+                "avg_launch_ms": round(kernel_ms, 4), "launches": launches,
                 "rays_per_launch": round(rays_per_launch)}
         hbm_alg = rays_per_launch * (B_STREAM + hit_frac * B_ATTR)
         hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "algorithmic_bytes_per_ray": round(B_STREAM + hit_frac * B_ATTR, 1),
+               "algorithmic_bytes_per_ray": round(B_STREAM + hit_frac * B_ATTR, 1), "hit_fraction": hit_frac, "hit_fraction_source": bray_file,
                "algorithmic_note": "SURVEY §8(d) without the geometry term: streams 188 B + 192 B x hit fraction; KD nodes / triangle records "
                                    f"(500 B per ray of the {B_RAY_CORNELL_ALL:.0f} B figure) are LDS-resident and never reach HBM",
                "achieved": round(hbm_alg / (kernel_ms * 1e-3) / 1e9, 1)}
@@ -259,13 +295,14 @@ def main():
                 "samples": f"{spp} spp per frame" + (f", sample indices split over {world} GPUs (strong scaling)" if world > 1 else ""),
                 "tiles": f"{spp} spp per frame" + (f", interleaved 64x64 tiles over {world} GPUs (strong scaling)" if world > 1 else "")}[mode]
         out = {
-            "metric": f"Msamples/sec, Cornell box {W}x{H}, {what}, {BOUNCES} bounces (camera paths traced per second)",
+            "metric": f"Msamples/sec, {'Cornell box' if headline else args.scene} {W}x{H}, {what}, {BOUNCES} bounces (camera paths traced per second)",
             "value": round(samples / dt / 1e6, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak" if mode == "weak" else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" + (" — REHEARSAL: all ranks share GPU 0, gloo reduce; not a measurement" if rehearsal else ""),
-            "config": {"workload": f"Cornell box (scenes/cornell-box/cornell.gltf) {W}x{H}, {spp_total} spp per frame, {BOUNCES} bounces "
-                                   f"(BASELINE.json configs[1]) on {world} x MI355X",
+            "config": {"workload": (f"Cornell box (scenes/cornell-box/cornell.gltf) {W}x{H}, {spp_total} spp per frame, {BOUNCES} bounces "
+                                    f"(BASELINE.json configs[1]) on {world} x MI355X") if headline else
+                                   f"{args.scene}: {stands_for}; {W}x{H}, {spp_total} spp per frame, {BOUNCES} bounces on {world} x MI355X",
                        "spp_total": spp_total,
                        "sharding": "none" if world == 1 else
                                    {"weak": "a sample range of its own per rank", "samples": "contiguous shares of the frame's sample indices per rank",
@@ -274,7 +311,17 @@ def main():
             "rays_per_sample": round(total_rays / samples, 4),
             "roofline": roof,
         }
-        if not args.no_psnr:
+        if world > 1:
+            out["rank_kernel_ms_per_frame"] = rank_kernel_ms      # integrator time per rank (HIP events): how evenly the tiles / samples were dealt
+            out["rank_kernel_ms_spread"] = round(max(rank_kernel_ms) / max(min(rank_kernel_ms), 1e-9), 4)
+        if world == 1 and headline and not args.no_configs:
+            # configs 3 / 4 / 5 + the textured asset: same process, after the timed loop and outside it (<= 60 s with the scene builds)
+            t_cfg = time.time()
+            del accum
+            torch.cuda.empty_cache()
+            out["configs"] = bench_configs.run_all(ptx, ctx)
+            out["configs_seconds"] = round(time.time() - t_cfg, 1)
+        if not args.no_psnr and headline:
             out.update(psnr_vs_oracle(ptx, scene, ctx))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

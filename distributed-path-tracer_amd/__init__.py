@@ -78,7 +78,7 @@ class RenderStats(C.Structure):
 
 class KernelTiming(C.Structure):
     _fields_ = [("pipeline", C.c_uint32), ("steps", C.c_uint32), ("classify_ms", C.c_double), ("traverse_ms", C.c_double), ("shade_ms", C.c_double),
-                ("fused_ms", C.c_double), ("fused_launches", C.c_uint32), ("reserved", C.c_uint32), ("pool_pairs", C.c_uint64),
+                ("fused_ms", C.c_double), ("fused_launches", C.c_uint32), ("pool_overflows", C.c_uint32), ("pool_pairs", C.c_uint64),
                 ("peak_pairs", C.c_uint64), ("slab_paths", C.c_uint64), ("workspace_bytes", C.c_uint64)]
 
 
@@ -210,7 +210,7 @@ class Context:
         """ptx_ctx_get_timing: where the time of the last render with stats went, and the workspace it used."""
         t = KernelTiming()
         _check(lib().ptx_ctx_get_timing(self.h, C.byref(t)))
-        return {n: getattr(t, n) for n, _ in KernelTiming._fields_ if n != "reserved"}
+        return {n: getattr(t, n) for n, _ in KernelTiming._fields_}
 
     def reduce_framebuffer(self, nccl_comm, accum, root=0):
         """ptx_reduce_framebuffer: in-place RCCL sum-reduce of a device-resident accumulation buffer onto `root`, on this

@@ -871,6 +871,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 				if (peak && n_big) sc->wf_pairs_per_ray = std::max(sc->wf_pairs_per_ray, (double)peak / (2.0 * n_big));
 				if (stats) { c->timing.peak_pairs = std::max<uint64_t>(c->timing.peak_pairs, peak); c->timing.slab_paths = std::max<uint64_t>(c->timing.slab_paths, n_big); }
 				if (overflow) {
+					if (stats) c->timing.pool_overflows++;
 					// some step needed more pairs than the pool holds: the same slabs again, smaller (the ratio just learnt says how much). The
 					// samples the aborted attempt already stored are stored again with the same values.
 					for (int k = 0; k < wf_sets; k++) HIP_TRY(hipStreamSynchronize(c->wf[k].stream));

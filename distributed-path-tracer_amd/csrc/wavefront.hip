@@ -872,7 +872,8 @@ static int wf_classify_grid(int n_cu) { return n_cu * 2; }   // persistent 1024-
 
 // PTX_WF_KERNEL=1 (measurement): the nested-loop form of the traverse kernel instead of the one-loop form
 static void launch_traverse(const DevScene& S, const WfBuffers& W, int n_cu, hipStream_t stream) {
-	static const bool nested = [] { const char* e = getenv("PTX_WF_KERNEL"); return e && e[0] == '1'; }();
+	const char* const e = getenv("PTX_WF_KERNEL");   // read per launch: the tests switch it inside one process
+	const bool nested = e && e[0] == '1';
 	// the one-loop kernel reads a leaf's records in place (leaf-ordered copy) at 32-bit offsets from the nodes
 	if (nested || !S.glb_leaf_ordered || S.geom_bytes > 0xFFFFFFFFull) hipLaunchKernelGGL(k_wf_traverse, dim3(wf_traverse_grid(n_cu)), dim3(kWfBlock), 0, stream, S, W, S.surfaces);
 	else hipLaunchKernelGGL(k_wf_traverse2, dim3(wf_traverse_grid(n_cu)), dim3(kWfBlock), 0, stream, S, W, S.surfaces);

@@ -202,7 +202,8 @@ typedef struct ptx_kernel_timing {
 	uint32_t steps;             /* queue-based pipeline: steps timed (classify + traverse + shade each) */
 	double classify_ms, traverse_ms, shade_ms;   /* sums over those steps */
 	double fused_ms;            /* fused kernel: sum over its launches */
-	uint32_t fused_launches, reserved;
+	uint32_t fused_launches;
+	uint32_t pool_overflows;    /* queue-based pipeline: slabs that were repeated smaller because a step's pairs did not fit the pool */
 	uint64_t pool_pairs;        /* queue-based pipeline: pairs (ray, entered surface) the pool holds, 48 bytes each */
 	uint64_t peak_pairs;        /* ... the most pairs one step of one slab asked for */
 	uint64_t slab_paths;        /* ... camera paths per slab */

@@ -279,7 +279,7 @@ static void mesh_finish(mesh& m) {
 
 struct mesh_hit { float t = -1; v3 bary{0, 0, 0}; uint32_t index = 0; };
 
-struct trav_stats { uint64_t branches = 0, leaves = 0, tris = 0, pushes = 0, mesh_tests = 0, model_tests = 0; uint64_t depth_hist[32] = {0}; };
+struct trav_stats { uint64_t branches = 0, leaves = 0, tris = 0, pushes = 0, mesh_tests = 0, model_tests = 0, hits = 0; uint64_t depth_hist[32] = {0}; };
 
 // mesh::intersect — mesh.cpp:300-405
 static mesh_hit mesh_intersect(const mesh& m, const ray& r, trav_stats* st) {
@@ -454,6 +454,7 @@ static scene_hit scene_intersect(const scene_t& s, const ray& r, trav_stats* st)
 		if (h.dist < nearest.dist || !(nearest.dist >= 0)) { nearest = h; nm = &md; }
 	}
 	if (!(nearest.dist >= 0)) return {};
+	if (st) st->hits++;
 	const mesh& m = s.surfaces[nearest.surface].m;
 	const vertex& v1 = m.verts[m.tris[3 * nearest.tri]];
 	const vertex& v2 = m.verts[m.tris[3 * nearest.tri + 1]];
@@ -1151,7 +1152,7 @@ void ora_primary_rays(void* p, const render_cfg* cfg, uint32_t sample, float* ou
 // mean_rgba: [h][w][4] float running mean exactly as renderer.cpp:396-399 (alpha = 1);
 // rows are distributed over `threads` std::threads (cf. the row jobs of renderer.cpp:357-402);
 // the result does not depend on the thread count (counter-based RNG).
-// stats: [0] = rays (renderer::intersect calls), [1..6] traversal counters when want_stats.
+// stats: [0] = rays (renderer::intersect calls), [1..7] traversal counters when want_stats ([7] = rays that hit a surface).
 void ora_render(void* p, const render_cfg* cfg, float* mean_rgba, int threads, uint64_t* stats, int want_stats) {
 	const scene_t& s = *(scene_t*)p;
 	if (threads < 1) threads = (int)std::thread::hardware_concurrency();
@@ -1180,11 +1181,11 @@ void ora_render(void* p, const render_cfg* cfg, float* mean_rgba, int threads, u
 	for (int t = 0; t < threads; t++) th.emplace_back(work, t);
 	for (auto& t : th) t.join();
 	if (stats) {
-		for (int k = 0; k < 7; k++) stats[k] = 0;
+		for (int k = 0; k < 8; k++) stats[k] = 0;
 		for (int t = 0; t < threads; t++) {
 			stats[0] += rays[t];
 			stats[1] += tst[t].model_tests; stats[2] += tst[t].mesh_tests; stats[3] += tst[t].branches;
-			stats[4] += tst[t].leaves; stats[5] += tst[t].tris; stats[6] += tst[t].pushes;
+			stats[4] += tst[t].leaves; stats[5] += tst[t].tris; stats[6] += tst[t].pushes; stats[7] += tst[t].hits;
 		}
 	}
 }

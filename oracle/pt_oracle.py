@@ -478,9 +478,9 @@ class OracleScene:
         return out
 
     def render(self, cfg, threads=0, stats=False):
-        """-> (mean_rgba [h,w,4] float32, stats uint64[7] = rays, model tests, mesh tests, branches, leaves, tris, pushes)"""
+        """-> (mean_rgba [h,w,4] float32, stats uint64[8] = rays, model tests, mesh tests, branches, leaves, tris, pushes, hits)"""
         img = np.zeros((cfg.h, cfg.w, 4), np.float32)
-        st = np.zeros(7, np.uint64)
+        st = np.zeros(8, np.uint64)
         lib().ora_render(self.h, C.byref(cfg), _p(img), C.c_int(threads), _p(st), C.c_int(1 if stats else 0))
         return img, st
 

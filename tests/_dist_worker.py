@@ -18,8 +18,13 @@ CORNELL = os.path.join(ROOT, "scenes", "cornell-box", "cornell.gltf")
 
 
 class OracleScene:
-    def __init__(self):
-        self.s = ora.OracleScene(ora.load_gltf(CORNELL))
+    def __init__(self, many_surfaces=False):
+        if many_surfaces:   # a Sponza-class stand-in: one model of 24 surfaces under the sun (BASELINE configs 4 / 5 shard by tiles)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from conftest import oracle_from_dict
+            self.s = oracle_from_dict(ora, importlib.import_module("distributed-path-tracer_amd.procedural").atrium_scene(1))
+        else:
+            self.s = ora.OracleScene(ora.load_gltf(CORNELL))
 
     def render(self, W, H, spp, bounces, accum=None, sample0=0, tile=None, shard=None, **kw):
         smp = self.s.render_samples(ora.make_cfg(W, H, spp, bounces, sample0=sample0, tile=tile), threads=2)   # [h,w,spp,3]
@@ -39,7 +44,12 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     accum = torch.zeros((H, W, 4), dtype=torch.float32)
-    if mode == "tiles":
+    if mode == "atrium":
+        W, H = 48, 32
+        accum = torch.zeros((H, W, 4), dtype=torch.float32)
+        st = mg.render_tiles(OracleScene(many_surfaces=True), W, H, 2, 5, accum, rank, world, tile=8)
+        assert st["samples"] == int(mg.tile_mask(rank, world, W, H, 8).sum()) * 2
+    elif mode == "tiles":
         mg.render_tiles(OracleScene(), W, H, 2 * spp, b, accum, rank, world, tile=8)   # 5 x 3 tiles of 8 x 8 on the 40 x 24 frame
     elif mode == "strong":
         mg.render_samples(OracleScene(), W, H, 2 * spp, b, accum, rank, world)

@@ -736,6 +736,102 @@ def test_queue_pipeline_frames_bitwise_equal_fused_kernel(ptx, ctx, integrator):
     _both_pipelines(jack, W=120, H=68, spp=2, bounces=5, integrator=integrator)
 
 
+def test_camera_rays_on_the_device_against_reference_vectors(scene, jack_scene, gold_vec, gold_jack):
+    """a2 (scene::camera::get_ray, camera.cpp:10-21) checked DIRECTLY on the device: ptx_camera_rays_batch runs the device function every
+    camera sample of the integrator kernels goes through, on the reference's own (ndc, ratio) grids: bit-for-bit the reference's rays."""
+    for sc, g in ((scene, gold_vec), (jack_scene, gold_jack)):
+        got = sc.camera_rays(g["cam_in"])
+        np.testing.assert_array_equal(_bits(got), _bits(g["cam_out"].reshape(-1, 6)))
+
+
+def test_fresh_context_fused_then_queue_based_then_fused(ptx):
+    """Regression for the fault of commit 3327259 (a null stream pointer in the fused kernel once the queue-based path had claimed the
+    workspace): a FRESH context whose first call is a fused-kernel render of a scene that keeps a global-memory copy, then the
+    queue-based pipeline, then the fused kernel again at a larger size. Every frame must come back, and the two pipelines agree bitwise."""
+    from conftest import product_from_dict
+    c2 = ptx.Context(0)
+    try:
+        atr = product_from_dict(ptx, c2, _proc().atrium_scene(2))
+        with _Pipeline(False):
+            a0, s0 = atr.render(96, 54, 2, 5)
+        with _Pipeline(True):
+            a1, s1 = atr.render(96, 54, 2, 5)
+        np.testing.assert_array_equal(_bits(a1), _bits(a0))
+        assert s1["rays"] == s0["rays"]
+        with _Pipeline(False):
+            b0, t0 = atr.render(320, 180, 3, 6)
+        with _Pipeline(True):
+            b1, t1 = atr.render(320, 180, 3, 6)
+        np.testing.assert_array_equal(_bits(b1), _bits(b0))
+        assert t1["rays"] == t0["rays"] and np.isfinite(b0).all()
+        atr.close()
+    finally:
+        c2.close()
+
+
+def test_two_shards_back_to_back_without_stats(ptx, scene):
+    """Two different shards rendered one after the other on ONE context with stats == NULL into device buffers (no sync between the
+    calls): the second call replaces the cached pixel list while the first one's kernels may still be reading it — the library must
+    order the two. Sum of the shards == the unsharded frame, bitwise."""
+    import torch
+    W, H, spp, b = 448, 256, 3, 4
+    full, _ = scene.render(W, H, spp, b)
+    for rep in range(3):
+        acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        for r in range(4):
+            scene.render(W, H, spp, b, accum=acc, shard=(r, 4, 32), want_stats=False)
+        scene.ctx.synchronize()
+        np.testing.assert_array_equal(acc.cpu().numpy(), full)
+
+
+def test_queue_pipeline_pool_overflow_nested_kernel_and_timing(ptx, ctx, monkeypatch):
+    """The pair pool is sized from demand: with a guess of the pairs per ray that is far too low (PTX_WF_RATIO_GUESS) and a small pool the
+    first slab overflows; the library repeats it in smaller slabs and the frame and the ray count are those of the fused kernel. The
+    nested-loop form of the traverse kernel (PTX_WF_KERNEL=1) gives the same frame as the one-loop form; ptx_ctx_get_timing reports the
+    per-kernel split and the workspace."""
+    from conftest import product_from_dict
+    kw = dict(W=480, H=270, spp=3, bounces=5)
+    with _Pipeline(False):
+        ref, rst = product_from_dict(ptx, ctx, _proc().atrium_scene(2)).render(**kw)
+    monkeypatch.setenv("PTX_WF_RATIO_GUESS", "0.25")
+    monkeypatch.setenv("PTX_WF_PAIRS_M", "1")
+    fresh = product_from_dict(ptx, ctx, _proc().atrium_scene(2))      # a scene whose pairs per ray have not been measured yet
+    with _Pipeline(True):
+        ctx.set_timing(True)
+        got, st = fresh.render(**kw)
+        tm = ctx.timing()
+        ctx.set_timing(False)
+    np.testing.assert_array_equal(_bits(got), _bits(ref))
+    assert st["rays"] == rst["rays"]
+    assert tm["pipeline"] == 1 and tm["steps"] > 0 and tm["traverse_ms"] > 0 and tm["classify_ms"] > 0 and tm["shade_ms"] > 0
+    assert tm["peak_pairs"] > 0 and tm["pool_pairs"] == 1 << 20 and tm["workspace_bytes"] > 0
+    assert tm["pool_overflows"] >= 1                               # the first attempt (the whole pass as one slab) did not fit the pool
+    monkeypatch.delenv("PTX_WF_RATIO_GUESS"); monkeypatch.delenv("PTX_WF_PAIRS_M")
+    monkeypatch.setenv("PTX_WF_KERNEL", "1")
+    with _Pipeline(True):
+        nested, nst = fresh.render(**kw)
+    np.testing.assert_array_equal(_bits(nested), _bits(ref))
+    assert nst["rays"] == rst["rays"]
+    rng = np.random.default_rng(5)
+    cam = fresh.array(ptx.ARR_CAMERA)
+    d = rng.standard_normal((50_000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    org = np.tile(cam[:3].astype(np.float32), (len(d), 1))
+    with _Pipeline(True):
+        h1 = fresh.intersect(org, d)
+    monkeypatch.delenv("PTX_WF_KERNEL")
+    with _Pipeline(True):
+        h0 = fresh.intersect(org, d)
+    for k in h0:
+        np.testing.assert_array_equal(np.asarray(h1[k]).view(np.uint32), np.asarray(h0[k]).view(np.uint32), err_msg=k)
+    with _Pipeline(False):
+        ctx.set_timing(True)
+        fresh.render(**kw)
+        assert ctx.timing()["pipeline"] == 0 and ctx.timing()["fused_ms"] > 0
+        ctx.set_timing(False)
+
+
 def test_queue_pipeline_intersections_bitwise_equal_fused_kernel(ptx, ctx):
     """ptx_intersect_batch through the queues (many-surface scenes by default) against the fused kernel: every output word equal, for
     camera rays, bounce rays off the hit points, rays that miss everything, axis-parallel and non-finite rays, and a batch that is

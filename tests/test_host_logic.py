@@ -482,6 +482,8 @@ def test_malformed_png_is_an_error_not_a_crash(ptx, tmp_path):
     assert attempt(png(31, 23, 8, 6, 0, zlib.compress(raw))) == "loaded"
     for bad in (b"", good[:8], png(2 ** 31 - 1, 2 ** 31 - 1, 8, 6, 0, zlib.compress(raw)), png(0, 0, 8, 6, 0, zlib.compress(raw)),
                 png(4096, 4096, 8, 6, 0, zlib.compress(raw)), png(31, 23, 8, 7, 0, zlib.compress(raw)), png(31, 23, 3, 6, 0, zlib.compress(raw)),
+                png(65535, 65535, 16, 6, 0, zlib.compress(raw)), png(65535, 65535, 16, 6, 1, zlib.compress(raw)),   # 32 GiB by the header, 3 KB of data: refused before any allocation
+                png(20000, 20000, 8, 6, 0, zlib.compress(raw)),
                 png(31, 23, 8, 6, 1, zlib.compress(raw)), png(31, 23, 8, 6, 0, zlib.compress(raw.replace(b"\0" + bytes(124), b"\x09" + bytes(124)))),
                 png(31, 23, 8, 6, 0, zlib.compress(raw[:100])), png(31, 23, 8, 6, 0, b"\x12\x34" * 50),
                 png(31, 23, 8, 3, 0, zlib.compress(b"".join(b"\0" + bytes([200] * 31) for _ in range(23)))),
@@ -613,6 +615,23 @@ def test_jpeg_refusals_and_malformed_files(ptx, tmp_path):
     with pytest.raises(ptx.PtxError) as e:
         _texture_scene(ptx, tmp_path, str(tmp_path / "cmyk.jpg"))
     assert e.value.code == ptx.ERR_UNSUPPORTED
+    # a scan that names a quantisation table no DQT segment defined: refused (the reader used to decode against uninitialised memory)
+    def segments(data):
+        out, i = [], 2
+        while i + 4 <= len(data) and data[i] == 0xFF and data[i + 1] != 0xDA:
+            n = (data[i + 2] << 8) | data[i + 3]
+            out.append((data[i + 1], i, i + 2 + n))
+            i += 2 + n
+        return out
+    dqt = [(a, b) for m, a, b in segments(src) if m == 0xDB]
+    assert dqt
+    stripped = bytearray(src)
+    for a, b in reversed(dqt):
+        del stripped[a:b]
+    (tmp_path / "nodqt.jpg").write_bytes(bytes(stripped))
+    with pytest.raises(ptx.PtxError) as e:
+        _texture_scene(ptx, tmp_path, str(tmp_path / "nodqt.jpg"))
+    assert e.value.code == ptx.ERR_PARSE
     rnd = random.Random(2)
     for k in range(80):
         b = bytearray(src)
