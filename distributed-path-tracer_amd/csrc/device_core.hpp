@@ -420,18 +420,16 @@ DEV bool best_offer(Best& b, const ModelRec& M, int model, V3 ld, int surf, cons
 
 struct Surf { V3 pos, nrm, tan; float u, v; };
 
-// attribute interpolation of renderer::intersect — core/renderer.cpp:688-715
+// attribute interpolation of renderer::intersect — core/renderer.cpp:688-715. One round of nine 16-byte fetches from the triangle's
+// hit record (flat_scene.hpp: HitRec); the sums are the reference's, term by term.
 DEV void hit_attributes(const DevScene& S, const ShadeRec& R, uint32_t tri, float b1, float b2, Surf& out) {
 	const float b0 = 1 - b1 - b2;
-	const float4 A = S.tris[3 * tri], B = S.tris[3 * tri + 1], C = S.tris[3 * tri + 2];   // TriRec (global: once per hit)
-	uint32_t ia = __float_as_uint(A.w), ib = __float_as_uint(B.w), ic = __float_as_uint(C.w);
-	float4 a0 = S.vattr[2 * ia], a1 = S.vattr[2 * ia + 1];
-	float4 c0 = S.vattr[2 * ic], c1 = S.vattr[2 * ic + 1];
-	float4 e0 = S.vattr[2 * ib], e1 = S.vattr[2 * ib + 1];
+	const float4* H = S.tris + 9 * (size_t)tri;
+	const float4 A = H[0], B = H[1], C = H[2], a0 = H[3], e0 = H[4], c0 = H[5], a1 = H[6], e1 = H[7], c1 = H[8];
 	V3 lp = mk(A.x, A.y, A.z) * b0 + mk(B.x, B.y, B.z) * b1 + mk(C.x, C.y, C.z) * b2;
 	out.pos = mulmv(R.basis, lp) + mk(R.origin[0], R.origin[1], R.origin[2]);
-	out.u = a0.w * b0 + e0.w * b1 + c0.w * b2;
-	out.v = a1.w * b0 + e1.w * b1 + c1.w * b2;
+	out.u = A.w * b0 + B.w * b1 + C.w * b2;
+	out.v = a0.w * b0 + e0.w * b1 + c0.w * b2;
 	out.nrm = normalize(mulmv(R.nmat, mk(a0.x, a0.y, a0.z) * b0 + mk(e0.x, e0.y, e0.z) * b1 + mk(c0.x, c0.y, c0.z) * b2));
 	out.tan = normalize(mulmv(R.nmat, mk(a1.x, a1.y, a1.z) * b0 + mk(e1.x, e1.y, e1.z) * b1 + mk(c1.x, c1.y, c1.z) * b2));
 }

@@ -42,6 +42,12 @@ struct TriIsect { float e2y, e1z, e2z, e1y; float e1x, e2x, ay, az; float ax, c3
 // ---- vertex attributes: 2 x float4 (32 B) — normal.xyz, u | tangent.xyz, v ----
 struct VertAttr { float nx, ny, nz, u, tx, ty, tz, v; };
 
+// ---- hit record: 9 x float4 (144 B) per triangle — everything renderer::intersect interpolates on a hit (renderer.cpp:688-715),
+// gathered per triangle so that a hit costs ONE round of fetches: corners + u | normals + v | tangents. (Fetching the corner
+// record first and the three vertices' attributes through its ids afterwards was two dependent rounds per shaded vertex.)
+struct HitRec { float a[3], ua, b[3], ub, c[3], uc, na[3], va, nb[3], vb, nc[3], vc, ta[3], p0, tb[3], p1, tc[3], p2; };
+static_assert(sizeof(HitRec) == 144, "HitRec layout");
+
 // ---- per-model record (scene::model + its entity's global transform) ----
 struct ModelRec {
 	float inv_basis[9];   // columns x,y,z of inverse(basis)            — transform::inverse, transform.cpp:33-36
@@ -133,6 +139,7 @@ struct FlatScene {
 	std::vector<TriRec> tris;            // corners + vertex ids (shading: attribute interpolation)
 	std::vector<TriIsect> tri_isect;     // intersection form (traversal)
 	std::vector<VertAttr> vattr;
+	std::vector<HitRec> hitrec;          // per triangle: what a hit interpolates (shading)
 	CameraRec camera{};
 	SunRec sun{};
 	uint32_t kd_max_depth = 0;

@@ -20,6 +20,19 @@
 
 namespace ptx {
 
+// PTX_CLK builds (tools/build_variant.sh clk -DPTX_CLK): where a wave's time goes, by s_memtime around regions that are closed with a
+// forced s_waitcnt — how long the wave itself sits on each class of memory access (SQ_WAIT_ANY says only that it waits). Lane 0 of
+// every wave adds its clocks (kilocycles) into the counters block; ptx_render prints them. Not compiled into the product.
+#ifdef PTX_CLK
+#define CLK_T0() const uint64_t clk_t0_ = __builtin_amdgcn_s_memtime()
+#define CLK_T1(k) do { clk[k] += __builtin_amdgcn_s_memtime() - clk_t0_; } while (0)
+#define CLK_WAIT() __builtin_amdgcn_s_waitcnt(0)
+#else
+#define CLK_T0() do { } while (0)
+#define CLK_T1(k) do { } while (0)
+#define CLK_WAIT() do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------ integrator kernel
 // One launch = `P.n_paths` camera paths (P.pass_spp samples of every tile pixel), all bounces.
 // Per wave and chunk of up to kChunk paths, every step is up to three sweeps over the wave's private stream:
@@ -45,11 +58,16 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 #ifdef PTX_PROF
 	Prof prof{};
 #endif
+#ifdef PTX_CLK
+	uint64_t clk[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 kernel, 1 chunk fetch, 2 EXTEND entry loads, 3 EXTEND sweep (rest), 4 set-aside lists, 5 SHADE entry + hit loads, 6 SHADE hit-record gathers, 7 SHADE rest
+	const uint64_t clk_start = __builtin_amdgcn_s_memtime();
+#endif
 
 	for (;;) {
 		// Guided self-scheduling: full chunks while plenty of paths are left, then chunks that shrink with what remains (a
 		// multiple of 64, at least 128), so that the waves of the launch run dry together instead of one chunk-time apart.
 		uint32_t first_lo = 0, first_hi = 0, take = 0;
+		CLK_T0();
 		if (lane == 0) {
 			const unsigned long long seen = __hip_atomic_load(B.chunk_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			const unsigned long long left = seen < P.n_paths ? P.n_paths - seen : 0ull;
@@ -65,6 +83,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 		first_lo = __builtin_amdgcn_readfirstlane(first_lo);
 		first_hi = __builtin_amdgcn_readfirstlane(first_hi);
 		take = __builtin_amdgcn_readfirstlane(take);
+		CLK_T1(1);
 		const uint64_t first = ((uint64_t)first_hi << 32) | first_lo;
 		if (first >= P.n_paths) break;
 		uint32_t n_in = (uint32_t)((P.n_paths - first) < (uint64_t)take ? (P.n_paths - first) : take);
@@ -82,6 +101,10 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 			const bool defer = SURF ? (S.n_surfaces >= 1 && S.n_surfaces <= (uint32_t)kMaxDeferModels)
 			                        : (S.n_models > 1 && S.n_models <= kMaxDeferModels);   // the list lengths live in the 64 lanes of one VGPR
 			uint32_t list_len = 0;   // lane u: entries in the deferred list of unit u (model, or surface in SURF kernels)
+#ifdef PTX_CLK
+			const uint64_t clk_sweep0 = __builtin_amdgcn_s_memtime();
+			const uint64_t clk_loads0 = clk[2];
+#endif
 			for (uint32_t base = 0; base < n_in; base += 64) {
 				const uint32_t i = base + lane;
 				const bool active = i < n_in;
@@ -106,6 +129,9 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 						d = mk(q1.x, q1.y, q1.z);
 					}
 				}
+#ifdef PTX_CLK
+				if (step > 0) { CLK_T0(); CLK_WAIT(); CLK_T1(2); }   // the wave sits here until its 64 stream entries have arrived
+#endif
 				SceneHit h;
 				if (!defer) { if (active) scene_traverse<MODE>(S, g, o, d, h, spill); }
 				else if constexpr (SURF) {
@@ -202,6 +228,11 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 				}
 				if (active) { hbuf[i] = make_float4(__int_as_float(h.surface), __uint_as_float(h.tri), h.b1, h.b2); if (defer && !SURF) raw(hdist)[i].x = h.dist; }
 			}
+#ifdef PTX_CLK
+			CLK_WAIT();
+			clk[3] += (__builtin_amdgcn_s_memtime() - clk_sweep0) - (clk[2] - clk_loads0);
+			const uint64_t clk_lists0 = __builtin_amdgcn_s_memtime();
+#endif
 			if (defer) {
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -267,6 +298,12 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				}
 			}
+#ifdef PTX_CLK
+			CLK_WAIT();
+			clk[4] += __builtin_amdgcn_s_memtime() - clk_lists0;
+			const uint64_t clk_shade0 = __builtin_amdgcn_s_memtime();
+			const uint64_t clk_sl0 = clk[5] + clk[6];
+#endif
 			rays += n_in > lane ? (n_in - lane + 63u) / 64u : 0u;  // rays this lane traced in the sweep
 			// the wave re-reads below what other lanes of this wave just wrote
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -286,6 +323,17 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 				if (active) {
 					PROF(9);
 					const float4 q0 = qin[i], q1 = qin[kChunk + i], q2 = qin[2 * kChunk + i], q3 = qin[3 * kChunk + i], hq = hbuf[i];
+#ifdef PTX_CLK
+					{ CLK_T0(); CLK_WAIT(); CLK_T1(5); }
+					{   // the hit record's nine 16-byte pieces, fetched here so that the wait for them has a region of its own (shade_vertex then finds them in L1)
+						CLK_T0();
+						float acc = 0;
+						if (__float_as_int(hq.x) >= 0) { const float4* Hh = S.tris + 9 * (size_t)__float_as_uint(hq.y); for (int k = 0; k < 9; k++) acc += Hh[k].w; }
+						CLK_WAIT();
+						if (acc == 1.2345e-30f) rays++;   // keeps the fetches alive
+						CLK_T1(6);
+					}
+#endif
 					o = mk(q0.x, q0.y, q0.z); id = __float_as_uint(q0.w);
 					d = mk(q1.x, q1.y, q1.z);
 					T = mk(q1.w, q2.x, q2.y);
@@ -327,6 +375,10 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef PTX_CLK
+			CLK_WAIT();
+			clk[7] += (__builtin_amdgcn_s_memtime() - clk_shade0) - (clk[5] + clk[6] - clk_sl0);
+#endif
 
 			// ---------------- SHADOW: any-hit sweep over the requests of this step
 			if constexpr (SUN) {
@@ -469,6 +521,10 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 	// ray counter: one atomic per wave
 	for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
 	if (lane == 0 && rays) atomicAdd(B.ray_counter, (unsigned long long)rays);
+#ifdef PTX_CLK
+	clk[0] = __builtin_amdgcn_s_memtime() - clk_start;
+	if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(B.ray_counter + 6 + k, (unsigned long long)(clk[k] >> 10));
+#endif
 #ifdef PTX_PROF
 	for (int k = 0; k < kProfRegions; k++) {
 		if (prof.t[k]) atomicAdd(B.ray_counter + 6 + 2 * k, (unsigned long long)prof.t[k]);       // counters block + 64 bytes

@@ -42,7 +42,7 @@ struct DevScene {
 	const MaterialRec* materials;
 	const uint2* nodes;      // KD nodes of all surfaces (global-memory traversal)
 	const uint32_t* refs;    // unused by the kernels since the global path reads leaf-ordered records; kept for ptx_scene_get_array parity
-	const float4* tris;   // 3 per triangle: corners + vertex ids (TriRec)
+	const float4* tris;   // 9 per triangle: the hit record (HitRec: corners + u, normals + v, tangents)
 	const float4* tri_isect; // global-memory traversal: one TriIsect per leaf reference, in leaf order, triangle id in word 10; same allocation as `nodes`, behind them
 	uint64_t geom_bytes;     // bytes of that allocation (nodes + records)
 	// resident copy (staged into LDS by MODE_LDS / MODE_HYBRID kernels): nodes, refs and one TriIsect per triangle of the
@@ -51,7 +51,7 @@ struct DevScene {
 	const uint32_t* res_refs;
 	const float4* res_tris;
 	uint32_t n_res_nodes, n_res_refs, n_res_tris;
-	const float4* vattr;  // 2 per vertex
+	const float4* vattr;  // unused by the kernels since the hit records carry the attributes; kept for inspection
 	const ShadeRec* shade; // 1 per surface
 	const SpaceRec* spaces; // distinct world->local transforms
 	const TexRec* tex;       // textures

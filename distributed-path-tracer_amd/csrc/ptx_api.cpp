@@ -109,6 +109,7 @@ struct ptx_scene {
 	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr, d_isect, d_shade, d_tex, d_texels, d_lut, d_spaces, d_model_space;
 	DevBuf d_res_nodes, d_res_refs, d_res_tris, d_texels_f;
 	DevScene dev{};
+	double lds_area_share = 0;     // share of the surfaces' box area (sum over surfaces) that belongs to LDS-resident surfaces: how much of what a ray can enter is served from LDS
 	double wf_pairs_per_ray = 0;   // queue-based pipeline: pairs (ray, entered surface) per ray seen so far on this scene, 0 = not yet measured
 	bool leaf_ordered = true; // global-memory copy of the triangle records: per leaf reference (true) or per triangle (false)
 	int mode = MODE_GLOBAL;   // where the traversal arrays live: MODE_GLOBAL / MODE_LDS / MODE_HYBRID (kernels.hip)
@@ -128,6 +129,16 @@ void decide_mode(ptx_scene* sc) {
 	else sc->mode = getenv("PTX_NO_HYBRID") ? MODE_GLOBAL : MODE_HYBRID;
 	if (sc->mode == MODE_GLOBAL) for (auto& sr : h.surfaces) sr.lds_root = 0xFFFFFFFFu;
 	sc->lds_bytes = sc->mode == MODE_GLOBAL ? 0 : h.res_bytes;
+	{
+		double all = 0, res = 0;
+		for (const SurfaceRec& sr : h.surfaces) {
+			const double ex = sr.bmax[0] - sr.bmin[0], ey = sr.bmax[1] - sr.bmin[1], ez = sr.bmax[2] - sr.bmin[2];
+			const double a = (ex > 0 && ey > 0 && ez > 0) ? 2 * (ex * ey + ey * ez + ex * ez) : 0;
+			all += a;
+			if (sr.lds_root != 0xFFFFFFFFu) res += a;
+		}
+		sc->lds_area_share = all > 0 ? res / all : 0;
+	}
 	// Leaf-ordered records duplicate a triangle once per leaf that references it (12x on deep SAH trees) and save a dependent fetch per
 	// test. Measured up to 144 MB of records (the 262 k-triangle atrium, against 25 MB per triangle + references): the leaf order still
 	// wins by 8 % — the dependent fetch costs more than the cache footprint (profiles/round2_ab_layout_blocksize.txt), so the threshold
@@ -150,7 +161,7 @@ int upload_scene(ptx_scene* sc) {
 	HIP_TRY(up(sc->d_models, h.models.data(), h.models.size() * sizeof(ModelRec), h.models.size() * sizeof(ModelRec)));
 	HIP_TRY(up(sc->d_materials, h.materials.data(), h.materials.size() * sizeof(MaterialRec), h.materials.size() * sizeof(MaterialRec)));
 	HIP_TRY(up(sc->d_refs, h.kd_refs.data(), h.kd_refs.size() * 4, pad16(h.kd_refs.size() * 4)));
-	HIP_TRY(up(sc->d_tris, h.tris.data(), h.tris.size() * 48, h.tris.size() * 48));
+	HIP_TRY(up(sc->d_tris, h.hitrec.data(), h.hitrec.size() * sizeof(HitRec), h.hitrec.size() * sizeof(HitRec)));
 	decide_mode(sc);   // sets SurfaceRec::lds_root: before the surface table goes up
 	HIP_TRY(up(sc->d_surfaces, h.surfaces.data(), h.surfaces.size() * sizeof(SurfaceRec), h.surfaces.size() * sizeof(SurfaceRec)));
 	// KD nodes and the global-memory triangle records share ONE allocation: the queue-based traverse kernel addresses both as
@@ -552,16 +563,26 @@ namespace {
 constexpr uint64_t kWfPoolPairs = 384ull << 20;
 constexpr uint64_t kWfBatchPairs = 32ull << 20;   // ... of a batch-intersect slice
 constexpr uint32_t kWfFlowWords = 64, kWfFlowRays = 58 /* 64-bit */, kWfFlowPeak = 60, kWfFlowOverflow = 63, kWfMaxRound = 56;   // flow words: [s] entries of step s of the round, then the pool's peak demand and the overflow word
-bool use_wavefront(const ptx_scene* sc) {
+bool wf_eligible(const ptx_scene* sc) {
 	const size_t n_surf = sc->host.surfaces.size();
 	if (n_surf == 0 || n_surf > (size_t)kWfMaxSurfaces) return false;
+	return sc->mode != MODE_LDS && sc->dev.tri_isect;   // LDS-resident scenes keep no global-memory copy of the traversal records
+}
+// Which pipeline renders a scene. The fused kernel is at its best when the geometry rays meet is in LDS; the queues, when it is in
+// global memory: lanes are compacted per (ray, surface) pair and more waves cover the fetch latency. Two static signs of the latter:
+// a model of eight or more surfaces (1.9 x on the 24-surface atrium), or little of the surfaces' box area being LDS-resident — the
+// share is 0.98 for Cornell + 82 k-triangle mesh and 0.86 for the plaza (walls / ground resident: the queues run them 0.57 x / 0.73 x),
+// 0.16 for the reference's jack-of-blades (1.08 x through the queues) and 0.08 for the atrium. PTX_WAVEFRONT=0/1 overrides
+// (measurement, tests); the fused kernel's own measurement switches keep it selected.
+int pipeline_choice(const ptx_scene* sc) {
+	if (!wf_eligible(sc)) return 0;
+	if (const char* e = getenv("PTX_WAVEFRONT")) return e[0] == '1' ? 1 : 0;
+	if (getenv("PTX_FORCE_GLOBAL") || getenv("PTX_NO_HYBRID")) return 0;
 	int32_t max_per_model = 0;
 	for (const ModelRec& mr : sc->host.models) max_per_model = std::max(max_per_model, mr.n_surfaces);
-	if (sc->mode == MODE_LDS || !sc->dev.tri_isect) return false;   // LDS-resident scenes keep no global-memory copy of the traversal records
-	bool on = max_per_model >= 8;
-	if (const char* e = getenv("PTX_WAVEFRONT")) on = e[0] == '1';
-	return on;
+	return (max_per_model >= 8 || sc->lds_area_share < 0.35) ? 1 : 0;
 }
+bool use_wavefront(const ptx_scene* sc) { return pipeline_choice(sc) == 1; }
 double wf_ratio_guess(const ptx_scene* sc) {
 	const double n_surf = (double)sc->host.surfaces.size();
 	if (sc->wf_pairs_per_ray > 0) return std::min(n_surf, sc->wf_pairs_per_ray * 1.15 + 0.05);
@@ -726,7 +747,13 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 	int wf_sets = 1;
 	uint64_t pool_pairs = kWfPoolPairs;
 	const uint64_t pass_paths = (uint64_t)pass_spp * n_pixels;
-	const uint32_t wf_round = (uint32_t)std::min<uint64_t>((uint64_t)cfg->bounces + 1u, kWfMaxRound);   // steps enqueued back to back: a path of b bounces lives b steps + one for its last sun sample
+	// steps enqueued back to back before the host looks at the flow words again. The grids of a round are sized for the entries the
+	// slab had when the round began (entries only ever get fewer): short rounds keep the later steps' grids close to what is alive —
+	// the shade kernel's workgroups beyond the entry count only read it and leave, but a 66 M-path slab has 259 K of them per launch —
+	// at the price of one host round trip (tens of microseconds) per round. PTX_WF_ROUND overrides (measurement).
+	uint32_t wf_round = 3;
+	if (const char* e = getenv("PTX_WF_ROUND")) wf_round = (uint32_t)std::max(1, atoi(e));
+	wf_round = (uint32_t)std::min<uint64_t>({(uint64_t)wf_round, (uint64_t)cfg->bounces + 1u, (uint64_t)kWfMaxRound});
 	const bool timing = stats && c->timing_on;
 	if (stats) c->timing = ptx_kernel_timing{};
 	auto slab_cap = [&]() -> uint32_t {   // paths of a slab: the pool must hold the pairs of its busiest step
@@ -821,7 +848,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 			while (first < P.n_paths) {
 				wf_cap = std::min(wf_cap, slab_cap());   // never above what the buffers were sized for
 				set_streams(wf_cap);
-				uint32_t n_slab[2] = {0, 0}, slab_first[2] = {0, 0};
+				uint32_t n_slab[2] = {0, 0}, slab_first[2] = {0, 0}, n_round[2] = {0, 0};   // paths of the slab, entries when the current round began
 				bool live[2] = {false, false};
 				int cur[2] = {0, 0};
 				for (int k = 0; k < wf_sets; k++) {
@@ -834,6 +861,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 					HIP_TRY(hipMemsetAsync(ws.flow.p, 0, kWfFlowWords * 4, ws.stream));
 					HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ws.flow.p, (int)n_slab[k], 1, ws.stream));   // flow[0] = entries of step 0
 					live[k] = P.bounces > 0;
+					n_round[k] = n_slab[k];
 				}
 				bool overflow = false;
 				uint64_t peak = 0;
@@ -848,7 +876,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 							WfBuffers W = WF[k];
 							W.ctl = (uint32_t*)ws.ctl.p + (size_t)st * kWfCtlWords;
 							W.n_in = flow + st;
-							HIP_TRY(launch_wf_step(sc->dev, P, W, wf_st[k][cur[k]], wf_st[k][cur[k] ^ 1], wf_cap, n_slab[k], slab_first[k], flow + st + 1, B.sample_rad, c->n_cu, ws.stream,
+							HIP_TRY(launch_wf_step(sc->dev, P, W, wf_st[k][cur[k]], wf_st[k][cur[k] ^ 1], wf_cap, n_round[k], slab_first[k], flow + st + 1, B.sample_rad, c->n_cu, ws.stream,
 							                       step_events()));
 							cur[k] ^= 1;
 						}
@@ -861,6 +889,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 						peak = std::max<uint64_t>(peak, ws.flow_host[kWfFlowPeak]);
 						if (ws.flow_host[kWfFlowOverflow]) { overflow = true; live[k] = false; continue; }
 						const uint32_t left = ws.flow_host[wf_round];
+						n_round[k] = left;
 						if (left == 0) live[k] = false;
 						else HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ws.flow.p, (int)left, 1, ws.stream));   // next round: flow[0] = what this one left
 					}
@@ -923,6 +952,14 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 			tm.classify_ms += t0; tm.traverse_ms += t1; tm.shade_ms += t2;
 			tm.steps++;
 		}
+#ifdef PTX_CLK
+		if (!wavefront) {
+			unsigned long long clk[8];
+			HIP_TRY(hipMemcpy(clk, (char*)c->counters.p + 64, sizeof clk, hipMemcpyDeviceToHost));
+			static const char* names[8] = {"kernel", "chunk_fetch", "extend_entry_loads", "extend_sweep_rest", "set_aside_lists", "shade_entry_hit_loads", "shade_hitrec_gathers", "shade_rest"};
+			for (int k = 0; k < 8; k++) fprintf(stderr, "CLK %-22s %12llu kcycles summed over waves (%.2f %% of the waves' time)\n", names[k], clk[k], 100.0 * clk[k] / (double)clk[0]);
+		}
+#endif
 #ifdef PTX_PROF
 		unsigned long long prof[2 * kProfRegions];
 		HIP_TRY(hipMemcpy(prof, (char*)c->counters.p + 64, sizeof prof, hipMemcpyDeviceToHost));

@@ -184,7 +184,7 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 	s.models.assign(n_models, ModelRec{});
 	s.surfaces.assign(n_surf, SurfaceRec{});
 	s.materials.assign(n_surf, MaterialRec{});
-	s.kd_nodes.clear(); s.kd_refs.clear(); s.tris.clear(); s.tri_isect.clear(); s.vattr.clear();
+	s.kd_nodes.clear(); s.kd_refs.clear(); s.tris.clear(); s.tri_isect.clear(); s.vattr.clear(); s.hitrec.clear();
 	s.kd_max_depth = 0;
 	s.any_texture = false;
 	s.any_alpha = false;
@@ -225,6 +225,10 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 			memcpy(pa[t].v, a, 12); memcpy(pb[t].v, b, 12); memcpy(pc[t].v, c, 12);
 			s.tris.push_back({a[0], a[1], a[2], (uint32_t)(v0 + ix[0]), b[0], b[1], b[2], (uint32_t)(v0 + ix[1]),
 			                  c[0], c[1], c[2], (uint32_t)(v0 + ix[2])});
+			// core::vertex = position(3) tex_coord(2) normal(3) tangent(3)
+			s.hitrec.push_back({{a[0], a[1], a[2]}, a[3], {b[0], b[1], b[2]}, b[3], {c[0], c[1], c[2]}, c[3],
+			                    {a[5], a[6], a[7]}, a[4], {b[5], b[6], b[7]}, b[4], {c[5], c[6], c[7]}, c[4],
+			                    {a[8], a[9], a[10]}, 0.f, {b[8], b[9], b[10]}, 0.f, {c[8], c[9], c[10]}, 0.f});
 			const float e1[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]}, e2[3] = {a[0] - c[0], a[1] - c[1], a[2] - c[2]};
 			TriIsect rec{e2[1], e1[2], e2[2], e1[1], e1[0], e2[0], a[1], a[2], a[0], e1[1] * e2[2] - e2[1] * e1[2], 0.f, 0.f};
 			const uint32_t gid = (uint32_t)(t0 + t);   // every record carries its global triangle id (what a hit reports)

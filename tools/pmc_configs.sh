@@ -23,7 +23,10 @@ import bench_configs
 out = "$OUT"
 res = {}
 for cfg in ("config3_mesh82k_1080p_8b", "config4_atrium_1080p_8b", "config5_atrium_4k_16b", "jack_of_blades_1080p_8b"):
-    tag = "k_wf_traverse" if "atrium" in cfg else "k_render_pass"
+    line0 = None
+    for l in open(f"{out}/{cfg}.sq1.log"):
+        if l.startswith("{") and cfg in l: line0 = json.loads(l)[cfg]
+    tag = "k_wf_traverse" if line0 and "queue" in line0.get("pipeline", "") else "k_render_pass"
     ctr = collections.defaultdict(float); n_launch = collections.defaultdict(int); dur = 0.0
     for f in glob.glob(f"{out}/{cfg}/*/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
