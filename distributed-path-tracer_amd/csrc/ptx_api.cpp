@@ -777,9 +777,13 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 		if (!c->wf_main_ev) HIP_TRY(hipEventCreateWithFlags(&c->wf_main_ev, hipEventDisableTiming));
 		auto allocate = [&]() -> hipError_t {
 			hipError_t e;
+			// the pool that is allocated: what the slab needs at the pairs per path this scene is expected to ask for (+ 10 %), not the
+			// whole budget — a scene whose rays enter few boxes (jack-of-blades: 0.3 pairs per ray) holds 2 GB of pairs, not 18
+			const uint64_t alloc_pairs = std::min<uint64_t>(pool_pairs, std::max<uint64_t>(16ull << 20, (uint64_t)((double)wf_cap * 2.0 * wf_ratio_guess(sc) * 1.1)));
 			for (int k = 0; k < wf_sets; k++) {
 				ptx_ctx::WfSet& w = c->wf[k];
-				if ((e = wf_workspace(c, k, 2 * (size_t)wf_cap, pool_pairs, n_surf, wf_round, WF[k])) != hipSuccess) return e;
+				if (w.qent.cap > 4 * alloc_pairs * 32) { w.qent.release(); w.pair_hit.release(); }   // held from a much hungrier scene: give it back
+				if ((e = wf_workspace(c, k, 2 * (size_t)wf_cap, alloc_pairs, n_surf, wf_round, WF[k])) != hipSuccess) return e;
 				WF[k].ray_counter = (unsigned long long*)((uint32_t*)w.flow.p + kWfFlowRays);   // rays of the slab: added to the total once the slab is through (an overflowing attempt is not counted)
 				if ((e = w.stream_buf.ensure((size_t)wf_cap * 14 * sizeof(float4))) != hipSuccess) return e;
 				if (!w.stream && (e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking)) != hipSuccess) return e;
@@ -941,7 +945,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 		stats->kernel_ms = ms;
 		ptx_kernel_timing& tm = c->timing;
 		tm.pipeline = wavefront ? 1u : 0u;
-		tm.pool_pairs = wavefront ? pool_pairs : 0;
+		tm.pool_pairs = wavefront ? WF[0].pool_cap : 0;
 		tm.workspace_bytes = wavefront ? wf_workspace_bytes(c) : c->queues.cap + c->spill.cap;
 		if (!wavefront) { tm.fused_ms = ms; tm.fused_launches = n_pass; }
 		for (size_t k = 0; k + 4 <= n_step_ev; k += 4) {

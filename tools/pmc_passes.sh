@@ -5,7 +5,7 @@
 # Usage (on the GPU box, from the repo root): tools/pmc_passes.sh <outdir> [spp] [script + args instead of bench.py, e.g. "tools/bench_scenes.py --only mesh6 --spp 8"]
 set -u
 R=$PWD; OUT=$R/${1:-gpurun_out/pmc}; SPP=${2:-64}
-CMD=${3:-"bench.py --steps 1 --warmup 0 --spp $SPP --no-cpu-baseline --no-psnr"}
+CMD=${3:-"bench.py --steps 1 --warmup 0 --spp $SPP --no-cpu-baseline --no-psnr --no-configs"}
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 run() { name=$1; shift
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/$CMD > $OUT/$name.log 2>&1
