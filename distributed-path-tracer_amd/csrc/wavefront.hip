@@ -10,7 +10,7 @@
 //                  slot) grouped by surface: pair space comes from a pool sized by demand, one reservation per tile of 1024 rays
 //   k_wf_traverse  persistent waves that eat the queues: every lane walks ONE pair's tree (core::mesh::intersect, mesh.cpp:300-405)
 //                  and takes the next pair as soon as its walk ends, so lanes stay busy whatever the walk lengths; 256-thread
-//                  blocks and a traversal-only register footprint give 5 waves per SIMD to cover the fetch latency; queues are
+//                  blocks and a traversal-only register footprint (70 VGPRs, 24 KB of LDS) give 6 waves per SIMD to cover the fetch latency; queues are
 //                  dealt to XCDs surface by surface so that each L2 sees a part of the geometry
 //   k_wf_merge_* / k_wf_shade   one ray per lane again: the ray's pair results in surface order = model::intersect's loop (first
 //                  surface wins ties on the local distance), then renderer::intersect's loop over models (first model wins ties on the
@@ -215,7 +215,8 @@ DEV int wf_surface_at(uint32_t xcd, uint32_t r, uint32_t n_surf) {
 	return u < n_surf ? (int)u : -1;
 }
 
-// Persistent 256-thread workgroups (94 VGPRs, no scratch, 5 waves per SIMD). Every lane walks ONE pair's tree (mesh.cpp:300-405, the
+// The nested-loop form (kept for measurement, PTX_WF_KERNEL=1, and for layouts the one-loop kernel does not read: per-triangle records,
+// geometry beyond 4 GB). Persistent 256-thread workgroups (75 VGPRs, no scratch, 6 waves per SIMD). Every lane walks ONE pair's tree (mesh.cpp:300-405, the
 // loop of mesh_traverse) and takes its next pair from the wave's LDS-staged unit as soon as the walk ends. A wave takes work one
 // SEGMENT (the entries one classify tile queued for one surface: contiguous, <= 1024) at a time with one atomic on the surface's
 // cursor, and stages it in units of 64 entries with coalesced loads — the entries carry the local ray and the result slot, nothing
@@ -868,7 +869,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_shade(DevScene S0, RenderParams
 }
 
 // ------------------------------------------------------------------------------------ launchers
-static int wf_classify_grid(int n_cu) { return n_cu * 2; }   // persistent 1024-thread workgroups (38 VGPRs: two per CU)
+static int wf_classify_grid(int n_cu) { return n_cu * 2; }   // persistent 1024-thread workgroups (51 VGPRs: two per CU)
 
 // PTX_WF_KERNEL=1 (measurement): the nested-loop form of the traverse kernel instead of the one-loop form
 static void launch_traverse(const DevScene& S, const WfBuffers& W, int n_cu, hipStream_t stream) {
