@@ -44,7 +44,9 @@ struct DevScene {
 	const uint32_t* refs;    // unused by the kernels since the global path reads leaf-ordered records; kept for ptx_scene_get_array parity
 	const float4* tris;   // 9 per triangle: the hit record (HitRec: corners + u, normals + v, tangents)
 	const float4* tri_isect; // global-memory traversal: one TriIsect per leaf reference, in leaf order, triangle id in word 10; same allocation as `nodes`, behind them
-	uint64_t geom_bytes;     // bytes of that allocation (nodes + records)
+	uint64_t geom_bytes;     // bytes of that allocation (nodes + records [+ nodes2])
+	const uint2* nodes2;     // nullptr, or the KD nodes in 2-level blocks (wavefront.hip: BLOCK2; built when PTX_WF_BLOCK2 is set at scene creation), same allocation
+	const uint2* roots2;     // [n_surfaces] root node contents for nodes2
 	// resident copy (staged into LDS by MODE_LDS / MODE_HYBRID kernels): nodes, refs and one TriIsect per triangle of the
 	// surfaces that fit, indices rewritten to be local to these arrays (SurfaceRec::lds_root)
 	const uint2* res_nodes;

@@ -182,8 +182,50 @@ int upload_scene(ptx_scene* sc) {
 			isect_bytes = h.tri_isect.size() * 48;
 		}
 	}
-	HIP_TRY(sc->d_nodes.ensure(nodes_bytes + std::max<size_t>(isect_bytes, 16)));
-	HIP_TRY(hipMemsetAsync(sc->d_nodes.p, 0, nodes_bytes + std::max<size_t>(isect_bytes, 16), c->stream));
+	// measurement (PTX_WF_BLOCK2 at scene creation): a second copy of the nodes in 2-level blocks (wavefront.hip: BLOCK2) — a branch at even
+	// depth owns three 16-byte pairs: its children, then the children of each child
+	std::vector<uint2> nodes2, roots2;
+	if (getenv("PTX_WF_BLOCK2") && sc->mode != MODE_LDS && sc->leaf_ordered) {
+		auto W1 = [](uint32_t old_w1, bool blockroot, uint32_t pair) { return (old_w1 & 15u) | (blockroot ? 16u : 0u) | (pair << 5); };
+		auto alloc_block = [&]() { const uint32_t pair = (uint32_t)(nodes2.size() / 2); nodes2.resize(nodes2.size() + 6, make_uint2(0, 0)); return pair; };
+		std::vector<std::pair<uint32_t, uint32_t>> work;   // (old index of an even-depth branch, first pair of its block)
+		for (const SurfaceRec& sr : h.surfaces) {
+			const KdNode r = h.kd_nodes[sr.kd_root];
+			if ((r.w1 & 3u) == KD_LEAF) { roots2.push_back(make_uint2(r.w0, r.w1)); continue; }
+			const uint32_t b = alloc_block();
+			roots2.push_back(make_uint2(r.w0, W1(r.w1, true, b)));
+			work.push_back({sr.kd_root, b});
+			while (!work.empty()) {
+				const auto [old, blk] = work.back();
+				work.pop_back();
+				const KdNode P = h.kd_nodes[old];
+				const uint32_t nk = ((P.w1 >> 2) & 1u) + ((P.w1 >> 3) & 1u), li = P.w1 >> 4;
+				for (uint32_t i = 0; i < nk; i++) {
+					const KdNode K = h.kd_nodes[li + i];
+					if ((K.w1 & 3u) == KD_LEAF) { nodes2[2 * (size_t)blk + i] = make_uint2(K.w0, K.w1); continue; }
+					const uint32_t kp = blk + 1 + i;   // the pair of K's children inside P's block
+					nodes2[2 * (size_t)blk + i] = make_uint2(K.w0, W1(K.w1, false, kp));
+					const uint32_t ng = ((K.w1 >> 2) & 1u) + ((K.w1 >> 3) & 1u), gi = K.w1 >> 4;
+					for (uint32_t j = 0; j < ng; j++) {
+						const KdNode G = h.kd_nodes[gi + j];
+						if ((G.w1 & 3u) == KD_LEAF) { nodes2[2 * (size_t)kp + j] = make_uint2(G.w0, G.w1); continue; }
+						const uint32_t b2 = alloc_block();
+						nodes2[2 * (size_t)kp + j] = make_uint2(G.w0, W1(G.w1, true, b2));
+						work.push_back({gi + j, b2});
+					}
+				}
+			}
+		}
+	}
+	const size_t isect_pad = (std::max<size_t>(isect_bytes, 16) + 255) & ~(size_t)255;
+	const size_t n2_bytes = nodes2.size() * 8 + (nodes2.empty() ? 0 : 64), r2_bytes = (roots2.size() * 8 + 255) & ~(size_t)255;
+	const size_t geom_total = nodes_bytes + isect_pad + (nodes2.empty() ? 0 : n2_bytes + r2_bytes);
+	HIP_TRY(sc->d_nodes.ensure(geom_total));
+	HIP_TRY(hipMemsetAsync(sc->d_nodes.p, 0, geom_total, c->stream));
+	if (!nodes2.empty()) {
+		HIP_TRY(hipMemcpyAsync((char*)sc->d_nodes.p + nodes_bytes + isect_pad, nodes2.data(), nodes2.size() * 8, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipMemcpyAsync((char*)sc->d_nodes.p + nodes_bytes + isect_pad + n2_bytes, roots2.data(), roots2.size() * 8, hipMemcpyHostToDevice, c->stream));
+	}
 	if (!h.kd_nodes.empty()) HIP_TRY(hipMemcpyAsync(sc->d_nodes.p, h.kd_nodes.data(), h.kd_nodes.size() * 8, hipMemcpyHostToDevice, c->stream));
 	if (isect_bytes)
 		HIP_TRY(hipMemcpyAsync((char*)sc->d_nodes.p + nodes_bytes, sc->leaf_ordered ? (const void*)leaf.data() : (const void*)h.tri_isect.data(), isect_bytes, hipMemcpyHostToDevice, c->stream));
@@ -216,7 +258,9 @@ int upload_scene(ptx_scene* sc) {
 	d.tris = (const float4*)sc->d_tris.p;
 	d.vattr = (const float4*)sc->d_vattr.p;
 	d.tri_isect = isect_bytes ? (const float4*)((const char*)sc->d_nodes.p + nodes_bytes) : nullptr;
-	d.geom_bytes = (uint64_t)nodes_bytes + isect_bytes;
+	d.geom_bytes = (uint64_t)geom_total;
+	d.nodes2 = nodes2.empty() ? nullptr : (const uint2*)((const char*)sc->d_nodes.p + nodes_bytes + isect_pad);
+	d.roots2 = nodes2.empty() ? nullptr : (const uint2*)((const char*)sc->d_nodes.p + nodes_bytes + isect_pad + n2_bytes);
 	d.res_nodes = (const uint2*)sc->d_res_nodes.p;
 	d.res_refs = (const uint32_t*)sc->d_res_refs.p;
 	d.res_tris = (const float4*)sc->d_res_tris.p;

@@ -29,6 +29,7 @@ constexpr int kWfClassifyBlock = (int)kWfTile;   // ... of the classify kernel: 
 #define PTX_WF_UNIT 64
 #endif
 constexpr uint32_t kWfUnit = PTX_WF_UNIT;  // queue entries a wave stages into its LDS slice at a time
+static_assert(kWfUnit >= 1 && kWfUnit <= 64, "a unit is staged by one pass of the wave's 64 lanes");
 #ifndef PTX_WF_LDS_STACK
 #define PTX_WF_LDS_STACK 8
 #endif
@@ -468,6 +469,11 @@ constexpr int kWfLdsStack2 = PTX_WF_LDS_STACK2;
 constexpr int kWfMaxStack = kRegStack + kSpillStack;   // entries a walk may set aside (the nested kernels' bound: 27 > mesh.hpp:34's 25 levels)
 struct alignas(8) NodePair { uint32_t x, y, z, w; };   // two adjacent 8-byte nodes: 8-byte aligned, fetched as one 16-byte load
 
+// BLOCK2 (measurement: PTX_WF_BLOCK2=1): the node array in 2-LEVEL BLOCKS (DevScene::nodes2, upload_scene: a branch at even depth owns 48
+// contiguous bytes = its child pair, then the child pairs of its two children) — a lane that stands on such a branch fetches the whole
+// block with the trip's three loads and makes TWO node steps in the trip: half the dependent fetches per descent, three times the
+// bytes per fetch. Node word 1 there: axis | has-left << 2 | has-right << 3 | block-root << 4 | child pair index << 5.
+template <bool BLOCK2>
 __global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffers W, const SurfaceRec* __restrict__ t_surfaces) {
 	DevScene S = S0;
 	S.surfaces = t_surfaces;
@@ -481,6 +487,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffer
 	uint4* const spill4 = reinterpret_cast<uint4*>(W.spill) + (size_t)(blockIdx.x * (kWfBlock / 64) + wave) * (kSpillStack * 64) + lane;
 	const unsigned char* const geom = reinterpret_cast<const unsigned char*>(S.nodes);
 	const uint32_t tri_off = (uint32_t)(reinterpret_cast<const unsigned char*>(S.tri_isect) - geom);   // same allocation (upload_scene)
+	[[maybe_unused]] const uint32_t n2_off = BLOCK2 ? (uint32_t)(reinterpret_cast<const unsigned char*>(S.nodes2) - geom) : 0u;
 	const uint32_t n_surf = S.n_surfaces;
 	const uint32_t n_order = ((n_surf + 7u) / 8u) * 8u;
 
@@ -520,7 +527,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffer
 							u = __builtin_amdgcn_readfirstlane(u);
 							if (u < 0) { more = false; break; }
 							unit_surf = u;
-							const uint2 r = S.nodes[S.surfaces[u].kd_root];
+							const uint2 r = BLOCK2 ? S.roots2[u] : S.nodes[S.surfaces[u].kd_root];
 							root_nd = make_uint2(__builtin_amdgcn_readfirstlane(r.x), __builtin_amdgcn_readfirstlane(r.y));
 						}
 						uint32_t g = 0;
@@ -594,37 +601,53 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffer
 		const uint32_t count = nd.y >> 2;   // of a leaf
 		const bool tri = busy && leaf && k < count;
 		// every lane fetches (no join, no copies): a lane with nothing to fetch reads the allocation's first 16 bytes
-		const uint32_t off = branch ? (nd.y >> 4) * 8u : (tri ? tri_off + (nd.x + k) * 48u : 0u);
+		const bool broot = BLOCK2 && branch && (nd.y & 16u);
+		const uint32_t off = branch ? (BLOCK2 ? n2_off + (nd.y >> 5) * 16u : (nd.y >> 4) * 8u) : (tri ? tri_off + (nd.x + k) * 48u : 0u);
 		const NodePair q0 = *reinterpret_cast<const NodePair*>(geom + off);
 		float4 r1, r2;
-		if (tri) { r1 = *reinterpret_cast<const float4*>(geom + off + 16u); r2 = *reinterpret_cast<const float4*>(geom + off + 32u); }
-		// ---- node step (mesh.cpp:327-370; see mesh_traverse)
+		if (tri || broot) { r1 = *reinterpret_cast<const float4*>(geom + off + 16u); r2 = *reinterpret_cast<const float4*>(geom + off + 32u); }
+		// ---- node step (mesh.cpp:327-370; see mesh_traverse): on `cur` with its child pair (kid0, kid1); `on` = the lane makes this step
+		bool descend = false, dead_end = false;
+		uint2 next_nd = nd;
+		bool next_is_kid0 = true;
+		auto node_step = [&](bool on, uint2 cur, uint2 kid0, uint2 kid1) {
+			const uint32_t axis = cur.y & 3u;
+			const float split = __uint_as_float(cur.x);
+			const float oa = sel3(o, axis), da = sel3(d, axis);
+			const float split_dist = (split - oa) / da;
+			const bool has_l = cur.y & 4u, has_r = cur.y & 8u;
+			const bool left_first = oa < split;
+			// children sit at slot 0 (left, or right when there is no left) and slot 1 (right when both exist): kid0 / kid1
+			const bool first_is_kid0 = left_first || !has_l, second_is_kid0 = !left_first || !has_l;
+			const bool has_first = left_first ? has_l : has_r, has_second = left_first ? has_r : has_l;
+			const bool outside = split_dist < 0 || split_dist > max_dist;           // only the near child (mesh.cpp:354-357)
+			const bool far_only = !outside && split_dist < min_dist;                 // only the far child (:358-361)
+			const bool both = on && !outside && !far_only;                           // near child now, far child set aside (:362-369)
+			const bool push = both && has_second && sp < kWfMaxStack;
+			if (push) {
+				WFPROF(7);
+				const uint2 c = second_is_kid0 ? kid0 : kid1;
+				const uint4 ent = make_uint4(c.x, c.y, __float_as_uint(split_dist), __float_as_uint(max_dist));
+				if (sp < kWfLdsStack2) s_stk[sp][threadIdx.x] = ent; else spill4[(sp - kWfLdsStack2) * 64] = ent;
+			}
+			sp += push ? 1 : 0;
+			max_dist = both ? split_dist : max_dist;
+			const bool has_next = far_only ? has_second : has_first;
+			const bool k0 = far_only ? second_is_kid0 : first_is_kid0;
+			descend = on ? has_next : descend;
+			dead_end = on ? !has_next : dead_end;
+			next_is_kid0 = on ? k0 : next_is_kid0;
+			next_nd = (on && has_next) ? (k0 ? kid0 : kid1) : next_nd;
+		};
 		if (branch) WFPROF(2);
-		const uint32_t axis = nd.y & 3u;
-		const uint2 kid0 = make_uint2(q0.x, q0.y), kid1 = make_uint2(q0.z, q0.w);
-		const float split = __uint_as_float(nd.x);
-		const float oa = sel3(o, axis), da = sel3(d, axis);
-		const float split_dist = (split - oa) / da;
-		const bool has_l = nd.y & 4u, has_r = nd.y & 8u;
-		const bool left_first = oa < split;
-		// children sit at li (left, or right when there is no left) and li + 1 (right when both exist): kid0 / kid1
-		const bool first_is_kid0 = left_first || !has_l, second_is_kid0 = !left_first || !has_l;
-		const bool has_first = left_first ? has_l : has_r, has_second = left_first ? has_r : has_l;
-		const bool outside = split_dist < 0 || split_dist > max_dist;           // only the near child (mesh.cpp:354-357)
-		const bool far_only = !outside && split_dist < min_dist;                 // only the far child (:358-361)
-		const bool both = branch && !outside && !far_only;                       // near child now, far child set aside (:362-369)
-		const bool push = both && has_second && sp < kWfMaxStack;
-		if (push) {
-			WFPROF(7);
-			const uint2 c = second_is_kid0 ? kid0 : kid1;
-			const uint4 ent = make_uint4(c.x, c.y, __float_as_uint(split_dist), __float_as_uint(max_dist));
-			if (sp < kWfLdsStack2) s_stk[sp][threadIdx.x] = ent; else spill4[(sp - kWfLdsStack2) * 64] = ent;
+		node_step(branch, nd, make_uint2(q0.x, q0.y), make_uint2(q0.z, q0.w));
+		if constexpr (BLOCK2) {
+			// second level of the block: the child just chosen is a branch, and its child pair came with the block
+			const bool two = broot && descend && (next_nd.y & 3u) != KD_LEAF;
+			if (two) WFPROF(2);
+			const float4 gk = next_is_kid0 ? r1 : r2;
+			node_step(two, next_nd, make_uint2(__float_as_uint(gk.x), __float_as_uint(gk.y)), make_uint2(__float_as_uint(gk.z), __float_as_uint(gk.w)));
 		}
-		sp += push ? 1 : 0;
-		max_dist = both ? split_dist : max_dist;
-		const bool has_next = far_only ? has_second : has_first;
-		const bool descend = branch && has_next;
-		const uint2 next_nd = (far_only ? second_is_kid0 : first_is_kid0) ? kid0 : kid1;
 		// ---- triangle test: nearest triangle of the leaf with t <= max_dist; ties keep the first (mesh.cpp:381-389)
 		if (tri) WFPROF(3);
 		const PRay pr = pack_ray(o, d);
@@ -637,7 +660,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffer
 		const bool leaf_done = tri && k1 == count;
 		const bool hit = leaf_done && best_t >= 0;
 		// ---- the walk ends with a hit, goes on to the next pending subtree (mesh.cpp:317-325), or ends with nothing
-		const bool need_pop = busy && ((branch && !has_next) || (leaf && !tri) || (leaf_done && !hit));   // `leaf && !tri`: an empty leaf (the builder makes none)
+		const bool need_pop = busy && ((branch && dead_end) || (leaf && !tri) || (leaf_done && !hit));   // `leaf && !tri`: an empty leaf (the builder makes none)
 		const bool miss = need_pop && sp == 0;
 		if (hit || miss) W.pair_hit[slot] = hit ? make_float4(best_t, __uint_as_float(best_tri), bb1, bb2) : make_float4(-1.0f, 0.f, 0.f, 0.f);
 		const bool pop = need_pop && sp > 0;
@@ -645,11 +668,11 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffer
 		sp -= pop ? 1 : 0;
 		uint4 ent = s_stk[sp < kWfLdsStack2 ? sp : 0][threadIdx.x];       // read by every lane; kept by the popping ones
 		if (__ballot(pop && sp >= kWfLdsStack2) != 0) { if (pop && sp >= kWfLdsStack2) ent = spill4[(sp - kWfLdsStack2) * 64]; }
-		nd = pop ? make_uint2(ent.x, ent.y) : (descend ? next_nd : nd);
+		nd = pop ? make_uint2(ent.x, ent.y) : ((branch && descend) ? next_nd : nd);
 		min_dist = pop ? __uint_as_float(ent.z) : min_dist;
 		max_dist = pop ? __uint_as_float(ent.w) : max_dist;
-		k = (pop || descend) ? 0u : (tri ? k1 : k);
-		best_t = (pop || descend) ? -1.0f : best_t;
+		k = (pop || (branch && descend)) ? 0u : (tri ? k1 : k);
+		best_t = (pop || (branch && descend)) ? -1.0f : best_t;
 		busy = busy && !hit && !miss;
 	}
 #ifdef PTX_WF_PROF
@@ -877,7 +900,8 @@ static void launch_traverse(const DevScene& S, const WfBuffers& W, int n_cu, hip
 	const bool nested = e && e[0] == '1';
 	// the one-loop kernel reads a leaf's records in place (leaf-ordered copy) at 32-bit offsets from the nodes
 	if (nested || !S.glb_leaf_ordered || S.geom_bytes > 0xFFFFFFFFull) hipLaunchKernelGGL(k_wf_traverse, dim3(wf_traverse_grid(n_cu)), dim3(kWfBlock), 0, stream, S, W, S.surfaces);
-	else hipLaunchKernelGGL(k_wf_traverse2, dim3(wf_traverse_grid(n_cu)), dim3(kWfBlock), 0, stream, S, W, S.surfaces);
+	else if (S.nodes2 && getenv("PTX_WF_BLOCK2")) hipLaunchKernelGGL(k_wf_traverse2<true>, dim3(wf_traverse_grid(n_cu)), dim3(kWfBlock), 0, stream, S, W, S.surfaces);
+	else hipLaunchKernelGGL(k_wf_traverse2<false>, dim3(wf_traverse_grid(n_cu)), dim3(kWfBlock), 0, stream, S, W, S.surfaces);
 }
 
 // One slice of a batch: W.ctl must be zeroed, W.n_in == nullptr (the slice's ray count is known to the host)

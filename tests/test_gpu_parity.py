@@ -832,6 +832,32 @@ def test_queue_pipeline_pool_overflow_nested_kernel_and_timing(ptx, ctx, monkeyp
         ctx.set_timing(False)
 
 
+def test_two_level_node_blocks_variant(ptx, ctx, monkeypatch):
+    """PTX_WF_BLOCK2=1 (measurement switch, read at scene creation and per launch): the traverse kernel fetches a 2-level block of
+    nodes (48 B) per dependent fetch and makes two node steps per trip. Same walks, same results: frame and hit records bitwise equal."""
+    from conftest import product_from_dict
+    kw = dict(W=200, H=120, spp=2, bounces=6)
+    with _Pipeline(False):
+        ref, rst = product_from_dict(ptx, ctx, _proc().atrium_scene(2)).render(**kw)
+    monkeypatch.setenv("PTX_WF_BLOCK2", "1")
+    blk = product_from_dict(ptx, ctx, _proc().atrium_scene(2))
+    with _Pipeline(True):
+        got, st = blk.render(**kw)
+    np.testing.assert_array_equal(_bits(got), _bits(ref))
+    assert st["rays"] == rst["rays"]
+    rng = np.random.default_rng(11)
+    cam = blk.array(ptx.ARR_CAMERA)
+    d = rng.standard_normal((40_000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    org = np.tile(cam[:3].astype(np.float32), (len(d), 1))
+    with _Pipeline(True):
+        h1 = blk.intersect(org, d)
+    with _Pipeline(False):
+        h0 = blk.intersect(org, d)
+    for k in h0:
+        np.testing.assert_array_equal(np.asarray(h1[k]).view(np.uint32), np.asarray(h0[k]).view(np.uint32), err_msg=k)
+
+
 def test_queue_pipeline_intersections_bitwise_equal_fused_kernel(ptx, ctx):
     """ptx_intersect_batch through the queues (many-surface scenes by default) against the fused kernel: every output word equal, for
     camera rays, bounce rays off the hit points, rays that miss everything, axis-parallel and non-finite rays, and a batch that is
