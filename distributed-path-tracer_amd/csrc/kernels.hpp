@@ -133,7 +133,10 @@ struct WfBuffers {
 // surface u's queue, [kWfCtlCur + 64 u] hand-out cursor of surface u's segments (256 bytes apart: two dozen hot counters in one
 // cache line serialised every hand-out of the chip in one L2 channel), [kWfCtlProf ..] PTX_WF_PROF region counters
 constexpr uint32_t kWfCtlSeg = 16, kWfCtlProf = 80, kWfCtlCur = 192, kWfCtlWords = kWfCtlCur + 64u * 64u;
-constexpr uint32_t kWfTile = 1024;   // rays per classify tile = threads of a classify workgroup
+#ifndef PTX_WF_TILE
+#define PTX_WF_TILE 1024
+#endif
+constexpr uint32_t kWfTile = PTX_WF_TILE;   // rays per classify tile = threads of a classify workgroup (measured: profiles/round3_wf_ab.txt)
 // One of the two path-stream buffers of a render slab (SoA of float4, `cap` entries per array)
 struct WfStream {
 	float4* q;   // [4][cap]: (origin, id | flags) (direction, T.x) (T.y, T.z, L.x, L.y) (L.z, depth << 16 | pass, RNG key pixel, RNG key sample) — the fused kernel's entry

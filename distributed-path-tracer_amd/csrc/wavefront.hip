@@ -892,7 +892,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_shade(DevScene S0, RenderParams
 }
 
 // ------------------------------------------------------------------------------------ launchers
-static int wf_classify_grid(int n_cu) { return n_cu * 2; }   // persistent 1024-thread workgroups (51 VGPRs: two per CU)
+static int wf_classify_grid(int n_cu) { return n_cu * (int)(2048u / kWfTile); }   // persistent 1024-thread workgroups (51 VGPRs: two per CU)
 
 // PTX_WF_KERNEL=1 (measurement): the nested-loop form of the traverse kernel instead of the one-loop form
 static void launch_traverse(const DevScene& S, const WfBuffers& W, int n_cu, hipStream_t stream) {
