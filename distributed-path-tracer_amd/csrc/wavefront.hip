@@ -98,9 +98,9 @@ __global__ void __launch_bounds__(kWfClassifyBlock) k_wf_classify(DevScene S0, S
 		// pass 1: the surfaces this ray enters (bit u of `mine`), and per surface the number of rays of this wave that enter it (lane u of `cnt`)
 		unsigned long long mine = 0;
 		uint32_t cnt = 0;
+		uint32_t cur_space = 0xFFFFFFFFu;   // the local ray is kept for the second pass: a scene of one ray space (one model, or models that
+		V3 lo = o, ld = d, inv = d;         // share a transform) computes it once per ray
 		{
-			uint32_t cur_space = 0xFFFFFFFFu;
-			V3 lo = o, ld = d, inv = d;
 			for (int m = 0; m < S.n_models; m++) {
 				const ModelRec& M = S.models[m];
 				const uint32_t spc = S.model_space[m];
@@ -178,8 +178,6 @@ __global__ void __launch_bounds__(kWfClassifyBlock) k_wf_classify(DevScene S0, S
 
 		// pass 2: the queue entries (local ray + result slot), grouped by surface
 		if (!over) {
-			uint32_t cur_space = 0xFFFFFFFFu;
-			V3 lo = o, ld = d, inv = d;
 			for (int m = 0; m < S.n_models; m++) {
 				const ModelRec& M = S.models[m];
 				const unsigned long long range = (M.n_surfaces >= 64 ? ~0ull : ((1ull << M.n_surfaces) - 1ull)) << M.first_surface;
