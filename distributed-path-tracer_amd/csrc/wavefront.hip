@@ -191,9 +191,11 @@ __global__ void __launch_bounds__(kWfClassifyBlock) k_wf_classify(DevScene S0, S
 					if (em == 0) continue;
 					const uint32_t b = __builtin_amdgcn_readlane(qb, u);
 					if (bit) {
-						const uint32_t slot = first + (uint32_t)__popcll(mine & ((1ull << u) - 1ull));
+						const uint32_t kk = (uint32_t)__popcll(mine & ((1ull << u) - 1ull));
 						const size_t e = (size_t)b + rank_in(em);
-						W.qent[2 * e] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(slot));
+						// (one store instruction per SURFACE has an eighth of its lanes on; collecting a ray's entries through LDS and writing them
+						// ray by ray — 14 instead of 48 store instructions per 64 rays — changed nothing: the stores are 15 % of this kernel)
+						W.qent[2 * e] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(first + kk));
 						W.qent[2 * e + 1] = make_float4(ld.x, ld.y, ld.z, 0.f);
 					}
 				}
