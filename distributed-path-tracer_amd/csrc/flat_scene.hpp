@@ -4,7 +4,7 @@
 // kd_tree_node, LIB/scene/entity.hpp, LIB/core/kd_tree.hpp:20-31). Here everything is a flat array:
 // fixed-size records for models / surfaces / materials (read with scalar loads: the loop index is
 // wave-uniform), 8-byte KD nodes, 4-byte leaf references and 48-byte triangle records (the three
-// arrays the kernels stage through LDS), and 32-byte vertex attribute records that stay in HBM/L2.
+// arrays the kernels stage through LDS), and 144-byte per-triangle hit records that stay in HBM/L2.
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -27,7 +27,7 @@ inline KdNode kd_make_branch(float split, uint32_t axis, bool has_l, bool has_r,
 }
 inline KdNode kd_make_leaf(uint32_t first_ref, uint32_t count) { return {first_ref, KD_LEAF | (count << 2)}; }
 
-// ---- triangle record: 3 x float4 (48 B, 16-B aligned so that each corner is one ds_read_b128) ----
+// ---- triangle corner record (host side only: counts and inspection; the device reads HitRec) ----
 // xyz = corner position (mesh-local space), w = bit pattern of the GLOBAL vertex id of that corner
 struct TriRec { float ax, ay, az; uint32_t ia; float bx, by, bz; uint32_t ib; float cx, cy, cz; uint32_t ic; };
 
@@ -38,9 +38,6 @@ struct TriRec { float ax, ay, az; uint32_t ia; float bx, by, bz; uint32_t ib; fl
 // Ordered for packed-fp32 math (v_pk_mul_f32 / v_pk_add_f32 take even-aligned register pairs): every pair the solve
 // multiplies lane-wise sits in one 8-byte slot, so the three LDS / global reads deliver it ready to use.
 struct TriIsect { float e2y, e1z, e2z, e1y; float e1x, e2x, ay, az; float ax, c3, p0, p1; };
-
-// ---- vertex attributes: 2 x float4 (32 B) — normal.xyz, u | tangent.xyz, v ----
-struct VertAttr { float nx, ny, nz, u, tx, ty, tz, v; };
 
 // ---- hit record: 9 x float4 (144 B) per triangle — everything renderer::intersect interpolates on a hit (renderer.cpp:688-715),
 // gathered per triangle so that a hit costs ONE round of fetches: corners + u | normals + v | tangents. (Fetching the corner
@@ -136,9 +133,8 @@ struct FlatScene {
 	std::vector<uint32_t> model_space;   // per model
 	std::vector<KdNode> kd_nodes;
 	std::vector<uint32_t> kd_refs;       // global triangle ids
-	std::vector<TriRec> tris;            // corners + vertex ids (shading: attribute interpolation)
+	std::vector<TriRec> tris;            // corners + vertex ids (host side: counts, inspection)
 	std::vector<TriIsect> tri_isect;     // intersection form (traversal)
-	std::vector<VertAttr> vattr;
 	std::vector<HitRec> hitrec;          // per triangle: what a hit interpolates (shading)
 	CameraRec camera{};
 	SunRec sun{};

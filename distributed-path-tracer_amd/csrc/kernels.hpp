@@ -53,7 +53,6 @@ struct DevScene {
 	const uint32_t* res_refs;
 	const float4* res_tris;
 	uint32_t n_res_nodes, n_res_refs, n_res_tris;
-	const float4* vattr;  // unused by the kernels since the hit records carry the attributes; kept for inspection
 	const ShadeRec* shade; // 1 per surface
 	const SpaceRec* spaces; // distinct world->local transforms
 	const TexRec* tex;       // textures

@@ -106,7 +106,7 @@ struct ptx_ctx {
 struct ptx_scene {
 	ptx_ctx* ctx = nullptr;
 	FlatScene host;
-	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_vattr, d_isect, d_shade, d_tex, d_texels, d_lut, d_spaces, d_model_space;
+	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_shade, d_tex, d_texels, d_lut, d_spaces, d_model_space;
 	DevBuf d_res_nodes, d_res_refs, d_res_tris, d_texels_f;
 	DevScene dev{};
 	double lds_area_share = 0;     // share of the surfaces' box area (sum over surfaces) that belongs to LDS-resident surfaces: how much of what a ray can enter is served from LDS
@@ -236,7 +236,6 @@ int upload_scene(ptx_scene* sc) {
 		HIP_TRY(up(sc->d_res_refs, h.res_refs.data(), h.res_refs.size() * 4, pad16(h.res_refs.size() * 4)));
 		HIP_TRY(up(sc->d_res_tris, h.res_tris.data(), h.res_tris.size() * 48, h.res_tris.size() * 48));
 	}
-	HIP_TRY(up(sc->d_vattr, h.vattr.data(), h.vattr.size() * 32, h.vattr.size() * 32));
 	HIP_TRY(up(sc->d_shade, h.shade.data(), h.shade.size() * sizeof(ShadeRec), h.shade.size() * sizeof(ShadeRec)));
 	HIP_TRY(up(sc->d_tex, h.textures.data(), h.textures.size() * sizeof(TexRec), h.textures.size() * sizeof(TexRec)));
 	HIP_TRY(up(sc->d_texels, h.texels.data(), h.texels.size(), pad16(h.texels.size())));
@@ -256,7 +255,6 @@ int upload_scene(ptx_scene* sc) {
 	d.nodes = (const uint2*)sc->d_nodes.p;
 	d.refs = (const uint32_t*)sc->d_refs.p;
 	d.tris = (const float4*)sc->d_tris.p;
-	d.vattr = (const float4*)sc->d_vattr.p;
 	d.tri_isect = isect_bytes ? (const float4*)((const char*)sc->d_nodes.p + nodes_bytes) : nullptr;
 	d.geom_bytes = (uint64_t)geom_total;
 	d.nodes2 = nodes2.empty() ? nullptr : (const uint2*)((const char*)sc->d_nodes.p + nodes_bytes + isect_pad);
@@ -290,7 +288,7 @@ int upload_scene(ptx_scene* sc) {
 }
 
 void release_scene_buffers(ptx_scene* sc) {
-	for (DevBuf* b : {&sc->d_models, &sc->d_surfaces, &sc->d_materials, &sc->d_nodes, &sc->d_refs, &sc->d_tris, &sc->d_vattr, &sc->d_isect, &sc->d_shade, &sc->d_tex,
+	for (DevBuf* b : {&sc->d_models, &sc->d_surfaces, &sc->d_materials, &sc->d_nodes, &sc->d_refs, &sc->d_tris, &sc->d_shade, &sc->d_tex,
 	                  &sc->d_texels, &sc->d_texels_f, &sc->d_lut, &sc->d_spaces, &sc->d_model_space, &sc->d_res_nodes, &sc->d_res_refs, &sc->d_res_tris})
 		b->release();
 }

@@ -184,18 +184,10 @@ void finalize_scene(FlatScene& s, const float* cam, const float* sun) {
 	s.models.assign(n_models, ModelRec{});
 	s.surfaces.assign(n_surf, SurfaceRec{});
 	s.materials.assign(n_surf, MaterialRec{});
-	s.kd_nodes.clear(); s.kd_refs.clear(); s.tris.clear(); s.tri_isect.clear(); s.vattr.clear(); s.hitrec.clear();
+	s.kd_nodes.clear(); s.kd_refs.clear(); s.tris.clear(); s.tri_isect.clear(); s.hitrec.clear();
 	s.kd_max_depth = 0;
 	s.any_texture = false;
 	s.any_alpha = false;
-
-	// vertex attribute records (global vertex ids)
-	const size_t nv = s.vertices.size() / 11;
-	s.vattr.resize(nv);
-	for (size_t i = 0; i < nv; i++) {
-		const float* v = &s.vertices[11 * i];
-		s.vattr[i] = {v[5], v[6], v[7], v[3], v[8], v[9], v[10], v[4]};
-	}
 
 	// Per surface: records (in surface order), then the SAH builds — the expensive part, independent of each other: in parallel, one
 	// surface per thread, and the top levels of a surface's own recursion on further threads when there are fewer surfaces than cores
