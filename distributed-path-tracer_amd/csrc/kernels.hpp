@@ -63,6 +63,7 @@ struct DevScene {
 	uint32_t any_texture;
 	int32_t env_tex;         // environment map (renderer::environment): texture index or -1
 	const uint32_t* model_space; // per model
+	const uint32_t* wf_order;    // [n_surfaces] queue-based pipeline: the surfaces in the order the traverse kernel starts their queues (upload_scene)
 	int32_t n_models;
 	uint32_t n_surfaces, n_nodes, n_refs, n_tris;
 	uint32_t any_alpha;

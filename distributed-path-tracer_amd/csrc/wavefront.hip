@@ -208,12 +208,12 @@ __global__ void __launch_bounds__(kWfClassifyBlock) k_wf_classify(DevScene S0, S
 // ------------------------------------------------------------------------------------ traverse
 // Visiting order of the queues for a workgroup on XCD x (workgroups are dealt to the 8 XCDs round-robin by blockIdx): first the
 // surfaces u with u % 8 == x, then those of XCD x + 1, ... — while work lasts, every L2 serves its own eighth of the trees.
-DEV int wf_surface_at(uint32_t xcd, uint32_t r, uint32_t n_surf) {
-	// r-th surface in the order above; rows of 8: surfaces {x, x+8, ..}, then {x+1, ..}, ...
+DEV int wf_surface_at(const uint32_t* __restrict__ order, uint32_t xcd, uint32_t r, uint32_t n_surf) {
+	// r-th surface in the order above; rows of 8: ranks {x, x+8, ..}, then {x+1, ..}, ... of `order` (DevScene::wf_order, upload_scene)
 	const uint32_t per = (n_surf + 7u) / 8u;
 	const uint32_t off = r / per, j = r % per;
 	const uint32_t u = ((xcd + off) & 7u) + 8u * j;
-	return u < n_surf ? (int)u : -1;
+	return u < n_surf ? (int)order[u] : -1;
 }
 
 // The nested-loop form (kept for measurement, PTX_WF_KERNEL=1, and for layouts the one-loop kernel does not read: per-triangle records,
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 						if (unit_surf < 0) {
 							int u = -1;
 							for (; order_pos < n_order; order_pos++) {
-								const int c = wf_surface_at(xcd, order_pos, n_surf);
+								const int c = wf_surface_at(S.wf_order, xcd, order_pos, n_surf);
 								if (c >= 0 && W.ctl[kWfCtlSeg + c] != 0) { u = c; break; }
 							}
 							u = __builtin_amdgcn_readfirstlane(u);
@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffer
 						if (unit_surf < 0) {
 							int u = -1;
 							for (; order_pos < n_order; order_pos++) {
-								const int c = wf_surface_at(xcd, order_pos, n_surf);
+								const int c = wf_surface_at(S.wf_order, xcd, order_pos, n_surf);
 								if (c >= 0 && W.ctl[kWfCtlSeg + c] != 0) { u = c; break; }
 							}
 							u = __builtin_amdgcn_readfirstlane(u);

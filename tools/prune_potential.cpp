@@ -71,3 +71,24 @@ extern "C" uint64_t prune_potential(void* p, size_t n, const float* rays, uint64
 	for (int k = 0; k < 4; k++) { out[3 * k] = W[k].nodes; out[3 * k + 1] = W[k].tris; out[3 * k + 2] = W[k].walks; }
 	return diff;
 }
+// per surface: out[u][5] = walks, node steps, triangle tests, steps of the longest walk, KD nodes of the tree
+extern "C" void surface_work(void* p, size_t n, const float* rays, uint64_t* out) {
+	const scene_t& s = *(scene_t*)p;
+	const float inf = std::numeric_limits<float>::infinity();
+	for (size_t i = 0; i < n; i++) {
+		const float* q = rays + 6 * i;
+		ray r{{q[0], q[1], q[2]}, {q[3], q[4], q[5]}};
+		for (const model& md : s.models) {
+			ray view = xray(r, md.inv);
+			if (!aabb_intersect(md.box, view).hit) continue;
+			for (int k = 0; k < md.n_surfaces; k++) {
+				const int u = md.first_surface + k;
+				work w;
+				walk(s.surfaces[u].m, view, inf, w);
+				out[5 * u] += w.walks; out[5 * u + 1] += w.nodes; out[5 * u + 2] += w.tris;
+				out[5 * u + 3] = std::max<uint64_t>(out[5 * u + 3], w.nodes + w.tris);
+				out[5 * u + 4] = s.surfaces[u].m.nodes.size();
+			}
+		}
+	}
+}

@@ -24,6 +24,11 @@ for gen in range(3):
     for k in range(4):
         print(json.dumps({"rays": ["camera", "bounce 1", "bounce 2"][gen], "n": n, "policy": names[k], "walks_per_ray": round(o[k, 2] / n, 2), "node_steps_per_ray": round(o[k, 0] / n, 1),
                           "tri_tests_per_ray": round(o[k, 1] / n, 1), "lane_loads_vs_reference": round((o[k, 0] + 3 * o[k, 1]) / (o[0, 0] + 3 * o[0, 1]), 3), "rays_with_other_result": int(diff)}))
+    if os.environ.get("SURFACES"):
+        so = np.zeros(5 * sc.n_surf, np.uint64)
+        L.surface_work(sc.h, C.c_size_t(n), rays.ctypes.data_as(C.c_void_p), so.ctypes.data_as(C.c_void_p))
+        for u, (w, nn, tt, mx, kd) in enumerate(so.reshape(-1, 5)):
+            print(json.dumps({"surface": u, "kd_nodes": int(kd), "pairs_per_ray": round(w / n, 3), "steps_per_pair": round((nn + tt) / max(w, 1), 1), "share_of_steps": round(float(nn + tt) / float(so.reshape(-1, 5)[:, 1:3].sum()), 3), "longest_walk": int(mx)}))
     hit, idx = sc.intersect(rays)
     m = idx >= 0
     pos, nrm = hit[m, 0:3], hit[m, 5:8]
