@@ -79,7 +79,7 @@ class RenderStats(C.Structure):
 class KernelTiming(C.Structure):
     _fields_ = [("pipeline", C.c_uint32), ("steps", C.c_uint32), ("classify_ms", C.c_double), ("traverse_ms", C.c_double), ("shade_ms", C.c_double),
                 ("fused_ms", C.c_double), ("fused_launches", C.c_uint32), ("pool_overflows", C.c_uint32), ("pool_pairs", C.c_uint64),
-                ("peak_pairs", C.c_uint64), ("slab_paths", C.c_uint64), ("workspace_bytes", C.c_uint64)]
+                ("peak_pairs", C.c_uint64), ("slab_paths", C.c_uint64), ("workspace_bytes", C.c_uint64), ("traverse_drain_frac", C.c_double)]
 
 
 class Rays(C.Structure):

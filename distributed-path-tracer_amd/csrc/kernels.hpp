@@ -128,11 +128,13 @@ struct WfBuffers {
 	uint32_t* peak;                // device word: the most pairs any step of the slab asked for (what the host sizes the next slab by)
 	uint2* spill;                  // [wf_traverse_grid * 4 waves][kSpillWords]
 	unsigned long long* ray_counter;   // nullptr, or where classify adds the number of rays it was given (render statistics)
+	uint32_t wave_clock;           // 1: every traverse wave that found work adds its run time to ctl[kWfCtlClock ..] (ptx_ctx_set_timing)
 };
 // control block of a step (uint32 words): [0] pairs reserved so far, [1] this step overflowed the pool, [kWfCtlSeg + u] segments of
 // surface u's queue, [kWfCtlCur + 64 u] hand-out cursor of surface u's segments (256 bytes apart: two dozen hot counters in one
 // cache line serialised every hand-out of the chip in one L2 channel), [kWfCtlProf ..] PTX_WF_PROF region counters
 constexpr uint32_t kWfCtlSeg = 16, kWfCtlProf = 80, kWfCtlCur = 192, kWfCtlWords = kWfCtlCur + 64u * 64u;
+constexpr uint32_t kWfCtlClock = kWfCtlProf + 72;   // [+0, +1] 64-bit sum of the working waves' run times (s_memtime ticks), [+2] such waves, [+3] the longest run
 #ifndef PTX_WF_TILE
 #define PTX_WF_TILE 1024
 #endif
@@ -144,7 +146,7 @@ struct WfStream {
 };
 // flags in the id word of a stream entry (ids are slab-local, < 2^28)
 constexpr uint32_t kWfIdMask = 0x0FFFFFFFu, kWfZombie = 1u << 31, kWfPending = 1u << 30, kWfRequest = 1u << 29;
-constexpr uint32_t kWfMaxSlab = 1u << 26;   // paths of a slab at most (the stream buffers of a slab take 224 bytes per path)
+constexpr uint32_t kWfMaxSlab = 1u << 27;   // paths of a slab at most: the whole 128 Mi-path pass (the stream buffers of a slab take 224 bytes per path; ids have 28 bits)
 constexpr int kWfMaxSurfaces = 64;   // surface masks are one 64-bit word
 // persistent 256-thread workgroups of the traverse kernel: as many as can be resident (70 VGPRs and 24 KB of LDS allow 6 per CU; 8 are launched).
 // PTX_WF_GRID=<workgroups per CU> (measurement): fewer leave room for another stream's kernels

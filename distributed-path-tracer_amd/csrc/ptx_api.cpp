@@ -620,11 +620,14 @@ namespace {
 // Pair space is a pool sized from DEMAND: `wf_pairs_per_ray` of the scene (what its rays were seen to need; before the first
 // measurement min(surfaces, 4)) plus a margin decides how many rays a pool of `pool_pairs` serves; a step that needs more raises the
 // overflow word and the slab / slice is repeated in smaller pieces with the ratio it reported.
-// pairs of a render's pool, 48 B each. Measured on the 24-surface atrium (3.2 pairs per ray, two rays per path and step; 1080p, 64 spp,
-// profiles/round3_wf_ab.txt): 128 Mi pairs (6 GB: 17 M-path slabs, 10 GB of workspace in all) 409 Msamples/s, 256 Mi 435, 384 Mi 447,
-// 512 Mi 452 — every step of a slab ends with a few waves finishing walks of hundreds of dependent fetches, and a larger slab has
-// fewer such ends per path. The default takes 384 Mi (18 GB of a 288 GB device) unless that is more than a sixth of the free memory.
-constexpr uint64_t kWfPoolPairs = 384ull << 20;
+// pairs of a render's pool, 48 B each. Measured on the 24-surface atrium (3.7 pairs per ray, two rays per path and step; 1080p, 64 spp):
+// 128 Mi pairs (6 GB: 17 M-path slabs, 10 GB of workspace in all) 409 Msamples/s, 256 Mi 435, 384 Mi 447, 512 Mi 452
+// (profiles/round3_wf_ab.txt), and with the queues started largest tree first 384 / 512 Mi 473 / 477, 1024 Mi — the whole 133 M-path
+// pass as ONE slab — 490-495 (profiles/round3_surface_order.txt): every step of a slab ends with a few waves finishing walks of
+// hundreds of dependent fetches, and a larger slab has fewer such ends per path (jack-of-blades, whose steps after the first are small:
+// 2300 -> 2850 Msamples/s from 66 M- to 133 M-path slabs). The default takes 1 Gi pairs (48 GB of a 288 GB device) unless that is more
+// than a sixth of the free memory; what is ALLOCATED follows the scene's demand (ptx_render: alloc_pairs).
+constexpr uint64_t kWfPoolPairs = 1024ull << 20;
 constexpr uint64_t kWfBatchPairs = 32ull << 20;   // ... of a batch-intersect slice
 constexpr uint32_t kWfFlowWords = 64, kWfFlowRays = 58 /* 64-bit */, kWfFlowPeak = 60, kWfFlowOverflow = 63, kWfMaxRound = 56;   // flow words: [s] entries of step s of the round, then the pool's peak demand and the overflow word
 bool wf_eligible(const ptx_scene* sc) {
@@ -675,6 +678,7 @@ hipError_t wf_workspace(ptx_ctx* c, int set, size_t rays, size_t pool, size_t n_
 	W.overflow = (uint32_t*)w.flow.p + kWfFlowOverflow;
 	W.peak = (uint32_t*)w.flow.p + kWfFlowPeak;
 	W.ray_counter = nullptr;
+	W.wave_clock = 0;
 	return hipSuccess;
 }
 size_t wf_workspace_bytes(const ptx_ctx* c) {
@@ -819,11 +823,13 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 	if (const char* e = getenv("PTX_WF_ROUND")) wf_round = (uint32_t)std::max(1, atoi(e));
 	wf_round = (uint32_t)std::min<uint64_t>({(uint64_t)wf_round, (uint64_t)cfg->bounces + 1u, (uint64_t)kWfMaxRound});
 	const bool timing = stats && c->timing_on;
+	double clock_busy = 0, clock_all = 0;   // queue-based pipeline with timing on: traverse waves' run times against waves x longest run, summed over launches
 	if (stats) c->timing = ptx_kernel_timing{};
 	auto slab_cap = [&]() -> uint32_t {   // paths of a slab: the pool must hold the pairs of its busiest step
 		const double per_path = 2.0 * wf_ratio_guess(sc);
 		const uint64_t by_pool = (uint64_t)std::max(65536.0, (double)pool_pairs / per_path);
-		const uint64_t cap = std::min<uint64_t>({(pass_paths + wf_sets - 1) / wf_sets, (uint64_t)kWfMaxSlab - 1, by_pool});
+		static const uint64_t max_slab = [] { const char* e = getenv("PTX_WF_MAX_SLAB_M"); return e ? std::min<uint64_t>((uint64_t)kWfIdMask, strtoull(e, nullptr, 10) << 20) : (uint64_t)kWfMaxSlab - 1; }();   // measurement
+		const uint64_t cap = std::min<uint64_t>({(pass_paths + wf_sets - 1) / wf_sets, max_slab, by_pool});
 		const uint64_t n_slabs = (pass_paths + cap - 1) / cap;   // slabs of equal size rather than full ones and a remainder
 		return (uint32_t)((pass_paths + n_slabs - 1) / n_slabs);
 	};
@@ -843,7 +849,9 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 			hipError_t e;
 			// the pool that is allocated: what the slab needs at the pairs per path this scene is expected to ask for (+ 10 %), not the
 			// whole budget — a scene whose rays enter few boxes (jack-of-blades: 0.3 pairs per ray) holds 2 GB of pairs, not 18
-			const uint64_t alloc_pairs = std::min<uint64_t>(pool_pairs, std::max<uint64_t>(16ull << 20, (uint64_t)((double)wf_cap * 2.0 * wf_ratio_guess(sc) * 1.1)));
+			// (in steps of 64 Mi pairs: the ratio learnt from one frame must not move the allocation by a few per cent in the next)
+			const uint64_t want_pairs = (uint64_t)((double)wf_cap * 2.0 * wf_ratio_guess(sc) * 1.1), step = want_pairs > (128ull << 20) ? (64ull << 20) : (16ull << 20);
+			const uint64_t alloc_pairs = std::min<uint64_t>(pool_pairs, std::max<uint64_t>(16ull << 20, (want_pairs + step - 1) / step * step));
 			for (int k = 0; k < wf_sets; k++) {
 				ptx_ctx::WfSet& w = c->wf[k];
 				if (w.qent.cap > 4 * alloc_pairs * 32) { w.qent.release(); w.pair_hit.release(); }   // held from a much hungrier scene: give it back
@@ -944,6 +952,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 							WfBuffers W = WF[k];
 							W.ctl = (uint32_t*)ws.ctl.p + (size_t)st * kWfCtlWords;
 							W.n_in = flow + st;
+							W.wave_clock = timing ? 1u : 0u;
 							HIP_TRY(launch_wf_step(sc->dev, P, W, wf_st[k][cur[k]], wf_st[k][cur[k] ^ 1], wf_cap, n_round[k], slab_first[k], flow + st + 1, B.sample_rad, c->n_cu, ws.stream,
 							                       step_events()));
 							cur[k] ^= 1;
@@ -955,6 +964,14 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 						ptx_ctx::WfSet& ws = c->wf[k];
 						HIP_TRY(hipStreamSynchronize(ws.stream));
 						peak = std::max<uint64_t>(peak, ws.flow_host[kWfFlowPeak]);
+						if (timing) {   // the traverse waves' own clocks of this round's steps (wavefront.hip: kWfCtlClock)
+							for (uint32_t st = 0; st < wf_round; st++) {
+								uint32_t ck[4];
+								HIP_TRY(hipMemcpy(ck, (uint32_t*)ws.ctl.p + (size_t)st * kWfCtlWords + kWfCtlClock, sizeof ck, hipMemcpyDeviceToHost));
+								const double sum = (double)(((uint64_t)ck[1] << 32) | ck[0]), all = (double)ck[2] * (double)ck[3];
+								clock_busy += sum; clock_all += all;
+							}
+						}
 						if (ws.flow_host[kWfFlowOverflow]) { overflow = true; live[k] = false; continue; }
 						const uint32_t left = ws.flow_host[wf_round];
 						n_round[k] = left;
@@ -1020,6 +1037,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 			tm.classify_ms += t0; tm.traverse_ms += t1; tm.shade_ms += t2;
 			tm.steps++;
 		}
+		tm.traverse_drain_frac = clock_all > 0 ? 1.0 - clock_busy / clock_all : 0.0;
 #ifdef PTX_CLK
 		if (!wavefront) {
 			unsigned long long clk[8];

@@ -509,6 +509,8 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffer
 	const uint64_t t_start = __builtin_amdgcn_s_memtime();
 	uint32_t walk_steps = 0, walk_max = 0;
 #endif
+	const uint64_t clock0 = W.wave_clock ? __builtin_amdgcn_s_memtime() : 0;
+	bool worked = false;
 
 	for (;;) {
 		WFPROF(0);
@@ -591,6 +593,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffer
 			if (!more) break;
 			continue;
 		}
+		worked = true;
 		if (busy) WFPROF(1);
 		// The trip itself is straight-line code under per-lane predicates: both kinds of step are computed by every lane and kept
 		// where they apply (selects). With branches around the two kinds, every state variable a kind updates was copied at every join
@@ -674,6 +677,12 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffer
 		k = (pop || (branch && descend)) ? 0u : (tri ? k1 : k);
 		best_t = (pop || (branch && descend)) ? -1.0f : best_t;
 		busy = busy && !hit && !miss;
+	}
+	if (W.wave_clock && worked && lane == 0) {   // how long this wave ran: the host compares the sum over waves with waves x the longest run
+		const uint64_t run = __builtin_amdgcn_s_memtime() - clock0;
+		atomicAdd(reinterpret_cast<unsigned long long*>(W.ctl + kWfCtlClock), (unsigned long long)run);
+		atomicAdd(&W.ctl[kWfCtlClock + 2], 1u);
+		atomicMax(&W.ctl[kWfCtlClock + 3], (uint32_t)(run > 0xFFFFFFFFull ? 0xFFFFFFFFull : run));
 	}
 #ifdef PTX_WF_PROF
 	for (int q = 0; q < 8; q++) {

@@ -208,6 +208,8 @@ typedef struct ptx_kernel_timing {
 	uint64_t peak_pairs;        /* ... the most pairs one step of one slab asked for */
 	uint64_t slab_paths;        /* ... camera paths per slab */
 	uint64_t workspace_bytes;   /* device memory the pipeline that ran holds on the context (streams, pool, queues) */
+	double traverse_drain_frac; /* queue-based pipeline, with timing on: share of the traverse launches' wave-time between a wave running out of work
+	                             * and the launch's last wave ending (the persistent waves' own clocks; 0 when not measured) */
 } ptx_kernel_timing;
 int ptx_ctx_set_timing(ptx_ctx* ctx, int on);
 int ptx_ctx_get_timing(ptx_ctx* ctx, ptx_kernel_timing* out);

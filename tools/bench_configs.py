@@ -14,7 +14,7 @@ HBM_PEAK_GBS, N_SIMD, MAX_CLOCK_GHZ = 8000.0, 1024, 2.4   # /opt/skills/guides/M
 CONFIGS = {
     "config3_mesh82k_1080p_8b": dict(scene="mesh6", W=1920, H=1080, bounces=8, spp=32, bray="cornell + 81 920",
                                      what="Cornell + 81 920-triangle displaced icosphere (stand-in for the ~70k-triangle bunny), 1920x1080, 8 bounces"),
-    "config4_atrium_1080p_8b": dict(scene="atrium", W=1920, H=1080, bounces=8, spp=32, bray="config 4 stand-in",
+    "config4_atrium_1080p_8b": dict(scene="atrium", W=1920, H=1080, bounces=8, spp=64, bray="config 4 stand-in",
                                     what="atrium: 262 176 triangles in 24 surfaces of one model, sun (stand-in for Sponza), 1920x1080, 8 bounces"),
     "config5_atrium_4k_16b": dict(scene="atrium", W=3840, H=2160, bounces=16, spp=16, bray="config 5 stand-in",
                                   what="the same scene, 3840x2160, 16 bounces"),
@@ -81,7 +81,8 @@ def run_config(ptx, ctx, name, cache, spp_scale=1.0, timing=True):
                     "kernel_ms": round(tm["traverse_ms"] / max(tm["steps"], 1), 4), "kernel_launches": tm["steps"], "kernel_total_ms": round(tm["traverse_ms"], 3),
                     "kernel_share_of_gpu_time": round(tm["traverse_ms"] / max(k_ms, 1e-9), 4),
                     "classify_total_ms": round(tm["classify_ms"], 3), "shade_total_ms": round(tm["shade_ms"], 3),
-                    "slab_paths": tm["slab_paths"], "pool_pairs": tm["pool_pairs"], "peak_pairs": tm["peak_pairs"], "workspace_gb": round(tm["workspace_bytes"] / 1e9, 2)})
+                    "slab_paths": tm["slab_paths"], "pool_pairs": tm["pool_pairs"], "peak_pairs": tm["peak_pairs"], "workspace_gb": round(tm["workspace_bytes"] / 1e9, 2),
+                    "traverse_drain_frac": round(tm["traverse_drain_frac"], 4)})
         kernel_s = tm["traverse_ms"] * 1e-3
     else:
         out.update({"pipeline": "fused persistent-wave kernel", "dominant_kernel": "k_render_pass", "kernel_ms": round(st["kernel_ms"] / max(st["passes"], 1), 4),
