@@ -628,7 +628,7 @@ namespace {
 // 2300 -> 2850 Msamples/s from 66 M- to 133 M-path slabs). The default takes 1 Gi pairs (48 GB of a 288 GB device) unless that is more
 // than a sixth of the free memory; what is ALLOCATED follows the scene's demand (ptx_render: alloc_pairs).
 constexpr uint64_t kWfPoolPairs = 1024ull << 20;
-constexpr uint64_t kWfBatchPairs = 32ull << 20;   // ... of a batch-intersect slice
+constexpr uint64_t kWfBatchPairs = 256ull << 20;   // ... of a batch-intersect slice at most (12 GB); sized by the batch
 constexpr uint32_t kWfFlowWords = 64, kWfFlowRays = 58 /* 64-bit */, kWfFlowPeak = 60, kWfFlowOverflow = 63, kWfMaxRound = 56;   // flow words: [s] entries of step s of the round, then the pool's peak demand and the overflow word
 bool wf_eligible(const ptx_scene* sc) {
 	const size_t n_surf = sc->host.surfaces.size();
@@ -1100,7 +1100,9 @@ int ptx_intersect_batch(ptx_scene* sc, const ptx_rays* r, size_t n, const ptx_hi
 		// queue-based pipeline, a slice of the batch at a time: as many rays as the pool serves at the pairs per ray this scene was seen
 		// to need; a slice whose pairs do not fit is repeated smaller (the ratio it reported is remembered on the scene)
 		const size_t n_surf = sc->host.surfaces.size();
-		uint64_t pool_pairs = kWfBatchPairs;
+		// the pool: what the whole batch is expected to need (in steps of 16 Mi pairs), at most kWfBatchPairs — one launch for a batch of
+		// up to ~60 M rays of a 24-surface scene; larger batches go in slices
+		uint64_t pool_pairs = std::min<uint64_t>(kWfBatchPairs, (((uint64_t)((double)n * wf_ratio_guess(sc) * 1.1) >> 24) + 1) << 24);
 		if (const char* e = getenv("PTX_WF_PAIRS_M")) pool_pairs = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;
 		auto slice_cap = [&]() { return (size_t)std::max(16384.0, (double)pool_pairs / wf_ratio_guess(sc)); };
 		size_t slice = std::min<size_t>(n, slice_cap());
