@@ -889,3 +889,44 @@ def test_queue_pipeline_intersections_bitwise_equal_fused_kernel(ptx, ctx):
         got = s.intersect(o_all, d_all)
     for k in ref:
         np.testing.assert_array_equal(np.asarray(got[k]).view(np.uint32), np.asarray(ref[k]).view(np.uint32), err_msg=k)
+
+
+def test_queue_start_order_wave_clock_and_sliced_batches(ptx, ctx, monkeypatch):
+    """The order in which the traverse kernel starts the surfaces' queues (largest tree first in renders, surface order in batches; the
+    PTX_WF_ORDER / PTX_WF_ORDER_BATCH switches are read at scene creation) only moves work in time: frames and hit records stay bitwise
+    those of the fused kernel. With timing on, ptx_ctx_get_timing also reports the share of the traverse waves' time spent between running
+    out of work and the end of their launch. A batch larger than the pair pool (PTX_WF_PAIRS_M=1) goes through in slices."""
+    from conftest import product_from_dict
+    kw = dict(W=240, H=136, spp=2, bounces=5)
+    with _Pipeline(False):
+        base = product_from_dict(ptx, ctx, _proc().atrium_scene(2))
+        ref, rst = base.render(**kw)
+    rng = np.random.default_rng(21)
+    cam = base.array(ptx.ARR_CAMERA)
+    n = 600_000
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    org = np.tile(cam[:3].astype(np.float32), (n, 1))
+    with _Pipeline(False):
+        h0 = base.intersect(org, d)
+    for order in ("0", "1", "2"):
+        monkeypatch.setenv("PTX_WF_ORDER", order)
+        monkeypatch.setenv("PTX_WF_ORDER_BATCH", order)
+        s = product_from_dict(ptx, ctx, _proc().atrium_scene(2))
+        with _Pipeline(True):
+            ctx.set_timing(True)
+            got, st = s.render(**kw)
+            tm = ctx.timing()
+            ctx.set_timing(False)
+            again, _ = s.render(**kw)
+            assert ctx.timing()["traverse_drain_frac"] == 0.0      # not measured without timing
+        np.testing.assert_array_equal(_bits(got), _bits(ref), err_msg="order " + order)
+        np.testing.assert_array_equal(_bits(again), _bits(ref))
+        assert st["rays"] == rst["rays"]
+        assert 0.0 < tm["traverse_drain_frac"] < 1.0
+        monkeypatch.setenv("PTX_WF_PAIRS_M", "1")     # 1 Mi pairs: this batch needs several slices
+        with _Pipeline(True):
+            h1 = s.intersect(org, d)
+        monkeypatch.delenv("PTX_WF_PAIRS_M")
+        for k in h0:
+            np.testing.assert_array_equal(np.asarray(h1[k]).view(np.uint32), np.asarray(h0[k]).view(np.uint32), err_msg=k + " order " + order)
