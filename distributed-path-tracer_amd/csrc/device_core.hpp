@@ -153,9 +153,13 @@ DEV void spill_get(const Spill& sp, int k, uint32_t& node, float& m) { uint2 v =
 // comparison distinguishes), so: fast path on v_min_f32 / v_max3_f32, exact compare-select path when the sum of
 // the six slab distances is NaN (which also catches inf - inf; taking the exact path then is merely slower).
 DEV bool aabb_test_inv(const float* mn, const float* mx, V3 o, V3 inv, float& nr, float& fr) {
-	if (mn[0] > mx[0] || mn[1] > mx[1] || mn[2] > mx[2]) return false;
-	const float ax = (mn[0] - o.x) * inv.x, ay = (mn[1] - o.y) * inv.y, az = (mn[2] - o.z) * inv.z;
-	const float bx = (mx[0] - o.x) * inv.x, by = (mx[1] - o.y) * inv.y, bz = (mx[2] - o.z) * inv.z;
+	// all six bounds are read before the first decision: the boxes sit in scalar-loaded tables, and a short-circuit `||` over
+	// mn[k] > mx[k] made three dependent scalar-load round trips out of one (the classify kernel's waves sat on s_waitcnt lgkmcnt
+	// three times per surface)
+	const float m0 = mn[0], m1 = mn[1], m2 = mn[2], x0 = mx[0], x1 = mx[1], x2 = mx[2];
+	if ((m0 > x0) | (m1 > x1) | (m2 > x2)) return false;
+	const float ax = (m0 - o.x) * inv.x, ay = (m1 - o.y) * inv.y, az = (m2 - o.z) * inv.z;
+	const float bx = (x0 - o.x) * inv.x, by = (x1 - o.y) * inv.y, bz = (x2 - o.z) * inv.z;
 	const float s = ((ax + bx) + (ay + by)) + (az + bz);
 	if (s == s) {
 		nr = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
