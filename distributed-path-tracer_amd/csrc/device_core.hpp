@@ -152,21 +152,47 @@ DEV void spill_get(const Spill& sp, int k, uint32_t& node, float& m) { uint2 v =
 // to it). Without a NaN, hardware v_min/v_max give the same values (up to the sign of a zero, which no later
 // comparison distinguishes), so: fast path on v_min_f32 / v_max3_f32, exact compare-select path when the sum of
 // the six slab distances is NaN (which also catches inf - inf; taking the exact path then is merely slower).
+// `b` = (min.x, max.x, min.y, max.y, min.z, max.z) (ModelRec / SurfaceRec::box): the six slab distances come out of three packed
+// subtractions and three packed multiplications on (min, max) pairs — the reference's IEEE operations on its operands, two at a time,
+// each pair one 64-bit scalar operand. The NaN test may sum them in any order (a NaN survives every order).
+// the hardware minimum / maximum as they are: fminf / fmaxf put a canonicalising v_max x, x in front of every operand (six per box), which
+// changes nothing on these operands (products, no NaN on this path)
+DEV float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEV float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEV float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+DEV float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// The unpacked form (fused kernels: they sit at their register cap, and the aligned pairs of the packed form cost them more in spills than
+// the halved multiplications give back: Cornell 1523 -> 1517 Msamples/s, profiles/round3_surface_order.txt)
 DEV bool aabb_test_inv(const float* mn, const float* mx, V3 o, V3 inv, float& nr, float& fr) {
-	// all six bounds are read before the first decision: the boxes sit in scalar-loaded tables, and a short-circuit `||` over
-	// mn[k] > mx[k] made three dependent scalar-load round trips out of one (the classify kernel's waves sat on s_waitcnt lgkmcnt
-	// three times per surface)
 	const float m0 = mn[0], m1 = mn[1], m2 = mn[2], x0 = mx[0], x1 = mx[1], x2 = mx[2];
 	if ((m0 > x0) | (m1 > x1) | (m2 > x2)) return false;
 	const float ax = (m0 - o.x) * inv.x, ay = (m1 - o.y) * inv.y, az = (m2 - o.z) * inv.z;
 	const float bx = (x0 - o.x) * inv.x, by = (x1 - o.y) * inv.y, bz = (x2 - o.z) * inv.z;
 	const float s = ((ax + bx) + (ay + by)) + (az + bz);
 	if (s == s) {
-		nr = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-		fr = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+		nr = hw_max3(hw_min(ax, bx), hw_min(ay, by), hw_min(az, bz));   // (fminf / fmaxf here: Cornell 1531 -> 1545 Msamples/s without their canonicalising)
+		fr = hw_min3(hw_max(ax, bx), hw_max(ay, by), hw_max(az, bz));
 	} else {
 		nr = pmax(pmax(pmin(ax, bx), pmin(ay, by)), pmin(az, bz));
 		fr = pmin(pmin(pmax(ax, bx), pmax(ay, by)), pmax(az, bz));
+	}
+	if (nr > fr) return false;
+	return fr >= 0;
+}
+DEV bool aabb_test_box(const float* b, V3 o, V3 inv, float& nr, float& fr) {
+	// all six bounds are read before the first decision: the boxes sit in scalar-loaded tables, and a short-circuit `||` made three
+	// dependent scalar-load round trips out of one
+	const f2 X = {b[0], b[1]}, Y = {b[2], b[3]}, Z = {b[4], b[5]};
+	if ((X.x > X.y) | (Y.x > Y.y) | (Z.x > Z.y)) return false;
+	const f2 tx = (X - bc(o.x)) * bc(inv.x), ty = (Y - bc(o.y)) * bc(inv.y), tz = (Z - bc(o.z)) * bc(inv.z);   // (a, b) of each axis
+	const f2 sm = (tx + ty) + tz;
+	const float s = sm.x + sm.y;
+	if (s == s) {
+		nr = hw_max3(hw_min(tx.x, tx.y), hw_min(ty.x, ty.y), hw_min(tz.x, tz.y));
+		fr = hw_min3(hw_max(tx.x, tx.y), hw_max(ty.x, ty.y), hw_max(tz.x, tz.y));
+	} else {
+		nr = pmax(pmax(pmin(tx.x, tx.y), pmin(ty.x, ty.y)), pmin(tz.x, tz.y));
+		fr = pmin(pmin(pmax(tx.x, tx.y), pmax(ty.x, ty.y)), pmax(tz.x, tz.y));
 	}
 	if (nr > fr) return false;
 	return fr >= 0;
@@ -378,10 +404,10 @@ DEV bool scene_occluded(const DevScene& S, const Geoms& g, V3 o, V3 d, const Spi
 // as a world distance, shortened by 1e-4 relative to cover every rounding on the way — lies beyond the closest hit the ray
 // already has, no candidate of the unit can win (candidates win on `<`, or on `==` with a lower id) and the traversal is
 // skipped; the result is bitwise what it would have been.
-DEV bool cannot_win(const float* pbmin, const float* pbmax, const float* basis, V3 lo, V3 ld, V3 inv, float best_wd) {
+DEV bool cannot_win(const float* pbox /* pbmin[3] then pbmax[3] */, const float* basis, V3 lo, V3 ld, V3 inv, float best_wd) {
 	if (!(best_wd >= 0)) return false;
 	float pn, pf;
-	if (!aabb_test_inv(pbmin, pbmax, lo, inv, pn, pf)) return true;    // misses even the grown box: nothing to find
+	if (!aabb_test_inv(pbox, pbox + 3, lo, inv, pn, pf)) return true;    // misses even the grown box: nothing to find
 	if (!(pn > 0)) return false;
 	return length(mulmv(basis, ld * pn)) * 0.9999f > best_wd;
 }

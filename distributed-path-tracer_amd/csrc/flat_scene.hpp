@@ -56,8 +56,11 @@ struct ModelRec {
 	int32_t first_surface, n_surfaces;
 	float pbmin[3], pbmax[3];  // the box grown by the reach of the +-epsilon barycentric slack: every point the triangle tests of this
 	                           // model can accept lies inside it (pruning of set-aside traversals, kernels.hip)
+	float pad0;
+	float box[6], pbox[6];     // the two boxes again as (min.x, max.x, min.y, max.y, min.z, max.z): the kernels' slab test works on (min, max)
+	                           // pairs with packed fp32 instructions and takes each pair as one 64-bit scalar operand (interleave_boxes)
 };
-static_assert(sizeof(ModelRec) == 47 * 4, "ModelRec layout");
+static_assert(sizeof(ModelRec) == 60 * 4, "ModelRec layout");
 
 // ---- per-surface record (model::surface = mesh + material) ----
 struct SurfaceRec {
@@ -67,7 +70,12 @@ struct SurfaceRec {
 	uint32_t lds_root;       // index of the root in the LDS-resident node array, 0xFFFFFFFF when the surface is not resident
 	uint32_t model;          // the model this surface belongs to
 	float pbmin[3], pbmax[3];  // mesh AABB grown by the reach of the barycentric slack (see ModelRec)
+	float box[6], pbox[6];     // both boxes as (min, max) pairs per axis (see ModelRec)
 };
+static_assert(sizeof(SurfaceRec) == 28 * 4, "SurfaceRec layout");
+template <class Rec> inline void interleave_boxes(Rec& r) {
+	for (int k = 0; k < 3; k++) { r.box[2 * k] = r.bmin[k]; r.box[2 * k + 1] = r.bmax[k]; r.pbox[2 * k] = r.pbmin[k]; r.pbox[2 * k + 1] = r.pbmax[k]; }
+}
 
 // ---- material factors (core/material.hpp:11-17) and texture slots ----
 struct MaterialRec {

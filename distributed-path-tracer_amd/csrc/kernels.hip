@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 								const V3 lo = mk(e0.x, e0.y, e0.z), ld = mk(e1.x, e1.y, e1.z);
 								const V3 inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
 								MeshHit mh;
-								if (!cannot_win(sf.pbmin, sf.pbmax, M.basis, lo, ld, inv, hd.x) && mesh_intersect_m<MODE, 10>(g, sf, lo, ld, inv, mh, spill PROF_PASS)) {
+								if (!cannot_win(sf.pbmin, M.basis, lo, ld, inv, hd.x) && mesh_intersect_m<MODE, 10>(g, sf, lo, ld, inv, mh, spill PROF_PASS)) {
 									Best b;
 									b.surf = __float_as_int(hr.x); b.tri = __float_as_uint(hr.y); b.b1 = hr.z; b.b2 = hr.w; b.wd = hd.x; b.tl = hd.y;
 									b.model = b.surf >= 0 ? (int)S.surfaces[b.surf].model : -1;   // per-lane table read, only on a hit
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 							const V3 lo = mk(e0.x, e0.y, e0.z), ld = mk(e1.x, e1.y, e1.z);
 							const V3 inv = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
 							float wd, b1, b2; int surf; uint32_t tri;
-							if (!cannot_win(M.pbmin, M.pbmax, M.basis, lo, ld, inv, bd) &&
+							if (!cannot_win(M.pbmin, M.basis, lo, ld, inv, bd) &&
 							    model_traverse<MODE, 10>(S, g, M, lo, ld, inv, wd, surf, tri, b1, b2, spill PROF_PASS) &&
 							    (wd < bd || !(bd >= 0) || (wd == bd && surf < bs))) {
 								hbuf[i] = make_float4(__int_as_float(surf), __uint_as_float(tri), b1, b2);

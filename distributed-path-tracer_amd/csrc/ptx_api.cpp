@@ -158,6 +158,8 @@ int upload_scene(ptx_scene* sc) {
 		if (e != hipSuccess) return e;
 		return bytes ? hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess;
 	};
+	for (ModelRec& mr : h.models) interleave_boxes(mr);
+	for (SurfaceRec& sr : h.surfaces) interleave_boxes(sr);
 	HIP_TRY(up(sc->d_models, h.models.data(), h.models.size() * sizeof(ModelRec), h.models.size() * sizeof(ModelRec)));
 	HIP_TRY(up(sc->d_materials, h.materials.data(), h.materials.size() * sizeof(MaterialRec), h.materials.size() * sizeof(MaterialRec)));
 	HIP_TRY(up(sc->d_refs, h.kd_refs.data(), h.kd_refs.size() * 4, pad16(h.kd_refs.size() * 4)));

@@ -106,12 +106,12 @@ __global__ void __launch_bounds__(kWfClassifyBlock) k_wf_classify(DevScene S0, S
 				const uint32_t spc = S.model_space[m];
 				if (spc != cur_space) { to_space(S.spaces[spc], o, d, lo, ld, inv); cur_space = spc; }
 				float nr, fr;
-				const bool enters = active && aabb_test_inv(M.bmin, M.bmax, lo, inv, nr, fr);   // model box first (model.cpp:38-40)
+				const bool enters = active && aabb_test_box(M.box, lo, inv, nr, fr);   // model box first (model.cpp:38-40)
 				if (__ballot(enters) == 0) continue;
 				for (int k = 0; k < M.n_surfaces; k++) {
 					const int u = M.first_surface + k;
 					const SurfaceRec& sf = S.surfaces[u];
-					const bool ent = enters && aabb_test_inv(sf.bmin, sf.bmax, lo, inv, nr, fr);
+					const bool ent = enters && aabb_test_box(sf.box, lo, inv, nr, fr);
 					const uint64_t em = __ballot(ent);
 					if (em == 0) continue;
 					if (ent) mine |= 1ull << u;
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse(DevScene S0, WfBuffers
 					const SurfaceRec& sf = S.surfaces[unit_surf];
 					const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 					float nr, fr;
-					if (aabb_test_inv(sf.bmin, sf.bmax, o, inv, nr, fr)) {   // mesh.cpp:308-315 (the classification saw the same test pass)
+					if (aabb_test_box(sf.box, o, inv, nr, fr)) {   // mesh.cpp:308-315 (the classification saw the same test pass)
 						busy = true; have = true;
 						node = sf.kd_root; min_dist = nr; max_dist = fr; fr0 = fr; sp = 0;
 					} else {
@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffer
 					const SurfaceRec& sf = S.surfaces[unit_surf];
 					const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 					float nr, fr;
-					if (aabb_test_inv(sf.bmin, sf.bmax, o, inv, nr, fr)) {   // mesh.cpp:308-315 (the classification saw the same test pass)
+					if (aabb_test_box(sf.box, o, inv, nr, fr)) {   // mesh.cpp:308-315 (the classification saw the same test pass)
 						busy = true;
 						nd = root_nd; min_dist = nr; max_dist = fr; sp = 0; k = 0; best_t = -1.0f;
 					} else {
