@@ -817,6 +817,7 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 	int wf_sets = 1;
 	uint64_t pool_pairs = kWfPoolPairs;
 	const uint64_t pass_paths = (uint64_t)pass_spp * n_pixels;
+	const double ratio_at_entry = sc->wf_pairs_per_ray;
 	// steps enqueued back to back before the host looks at the flow words again. The grids of a round are sized for the entries the
 	// slab had when the round began (entries only ever get fewer): short rounds keep the later steps' grids close to what is alive —
 	// the shade kernel's workgroups beyond the entry count only read it and leave, but a 66 M-path slab has 259 K of them per launch —
@@ -835,36 +836,36 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 		const uint64_t n_slabs = (pass_paths + cap - 1) / cap;   // slabs of equal size rather than full ones and a remainder
 		return (uint32_t)((pass_paths + n_slabs - 1) / n_slabs);
 	};
+	auto allocate = [&]() -> hipError_t {
+		hipError_t e;
+		// the pool that is allocated: what the slab needs at the pairs per path this scene is expected to ask for (+ 10 %), not the
+		// whole budget — a scene whose rays enter few boxes (jack-of-blades: 0.3 pairs per ray) holds 2 GB of pairs, not 18
+		// (in steps of 64 Mi pairs: the ratio learnt from one frame must not move the allocation by a few per cent in the next)
+		const uint64_t want_pairs = (uint64_t)((double)wf_cap * 2.0 * wf_ratio_guess(sc) * 1.1), step = want_pairs > (128ull << 20) ? (64ull << 20) : (16ull << 20);
+		const uint64_t alloc_pairs = std::min<uint64_t>(pool_pairs, std::max<uint64_t>(16ull << 20, (want_pairs + step - 1) / step * step));
+		for (int k = 0; k < wf_sets; k++) {
+			ptx_ctx::WfSet& w = c->wf[k];
+			if (w.qent.cap > 4 * alloc_pairs * 32) { w.qent.release(); w.pair_hit.release(); }   // held from a much hungrier scene: give it back
+			if ((e = wf_workspace(c, k, 2 * (size_t)wf_cap, alloc_pairs, n_surf, wf_round, WF[k])) != hipSuccess) return e;
+			WF[k].ray_counter = (unsigned long long*)((uint32_t*)w.flow.p + kWfFlowRays);   // rays of the slab: added to the total once the slab is through (an overflowing attempt is not counted)
+			if ((e = w.stream_buf.ensure((size_t)wf_cap * 14 * sizeof(float4))) != hipSuccess) return e;
+			if (!w.stream && (e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking)) != hipSuccess) return e;
+			if (!w.done && (e = hipEventCreateWithFlags(&w.done, hipEventDisableTiming)) != hipSuccess) return e;
+		}
+		return hipSuccess;
+	};
 	if (wavefront) {
 		{
 			size_t free_b = 0, total_b = 0;
 			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-				const uint64_t held = c->wf[0].qent.cap + c->wf[0].pair_hit.cap;   // what the context already holds counts as available
-				pool_pairs = std::min<uint64_t>(pool_pairs, std::max<uint64_t>(16ull << 20, (free_b + held) / 6 / 48));
+				const uint64_t held = wf_workspace_bytes(c);   // what the context already holds counts as available: the same answer frame after frame
+				pool_pairs = std::min<uint64_t>(pool_pairs, std::max<uint64_t>(16ull << 20, (free_b + held) / 4 / 48));
 			} else (void)hipGetLastError();
 		}
 		if (const char* e = getenv("PTX_WF_PAIRS_M")) pool_pairs = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;   // measurement: pool size in Mi pairs
 		pool_pairs = std::min<uint64_t>(pool_pairs, 0xFFFFFFFFull);
 		wf_sets = getenv("PTX_WF_TWO_STREAMS") ? 2 : 1;   // measurement: two slabs side by side on two streams
 		if (!c->wf_main_ev) HIP_TRY(hipEventCreateWithFlags(&c->wf_main_ev, hipEventDisableTiming));
-		auto allocate = [&]() -> hipError_t {
-			hipError_t e;
-			// the pool that is allocated: what the slab needs at the pairs per path this scene is expected to ask for (+ 10 %), not the
-			// whole budget — a scene whose rays enter few boxes (jack-of-blades: 0.3 pairs per ray) holds 2 GB of pairs, not 18
-			// (in steps of 64 Mi pairs: the ratio learnt from one frame must not move the allocation by a few per cent in the next)
-			const uint64_t want_pairs = (uint64_t)((double)wf_cap * 2.0 * wf_ratio_guess(sc) * 1.1), step = want_pairs > (128ull << 20) ? (64ull << 20) : (16ull << 20);
-			const uint64_t alloc_pairs = std::min<uint64_t>(pool_pairs, std::max<uint64_t>(16ull << 20, (want_pairs + step - 1) / step * step));
-			for (int k = 0; k < wf_sets; k++) {
-				ptx_ctx::WfSet& w = c->wf[k];
-				if (w.qent.cap > 4 * alloc_pairs * 32) { w.qent.release(); w.pair_hit.release(); }   // held from a much hungrier scene: give it back
-				if ((e = wf_workspace(c, k, 2 * (size_t)wf_cap, alloc_pairs, n_surf, wf_round, WF[k])) != hipSuccess) return e;
-				WF[k].ray_counter = (unsigned long long*)((uint32_t*)w.flow.p + kWfFlowRays);   // rays of the slab: added to the total once the slab is through (an overflowing attempt is not counted)
-				if ((e = w.stream_buf.ensure((size_t)wf_cap * 14 * sizeof(float4))) != hipSuccess) return e;
-				if (!w.stream && (e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking)) != hipSuccess) return e;
-				if (!w.done && (e = hipEventCreateWithFlags(&w.done, hipEventDisableTiming)) != hipSuccess) return e;
-			}
-			return hipSuccess;
-		};
 		// when the device cannot spare the pool: a smaller one (smaller slabs), and below 8 Mi pairs the fused kernel
 		for (;;) {
 			wf_cap = slab_cap();
@@ -1003,6 +1004,14 @@ int ptx_render(ptx_scene* sc, const ptx_render_cfg* cfg, float* accum, ptx_rende
 			for (int k = 0; k < wf_sets; k++) {
 				HIP_TRY(hipEventRecord(c->wf[k].done, c->wf[k].stream));
 				HIP_TRY(hipStreamWaitEvent(c->stream, c->wf[k].done, 0));
+			}
+			if (ratio_at_entry == 0 && sc->wf_pairs_per_ray > 0 && p + 1 == n_pass) {
+				// the scene's first frame has just told what its rays need: bring the workspace to the size the NEXT frame of this kind
+				// will ask for now (a larger slab, a smaller or larger pool), inside the frame that pays for allocations anyway
+				for (int k = 0; k < wf_sets; k++) HIP_TRY(hipStreamSynchronize(c->wf[k].stream));
+				wf_cap = slab_cap();
+				const hipError_t se = allocate();
+				if (se != hipSuccess) (void)hipGetLastError();   // not fatal: the next frame sizes its workspace itself
 			}
 		} else {
 			if (!B.queues || !B.sample_rad || !B.spill) return set_err(PTX_ERR_HIP, "ptx_render: workspace of the fused kernel is not allocated");

@@ -60,10 +60,13 @@ def run_config(ptx, ctx, name, cache, spp_scale=1.0, timing=True):
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{ctx.device}")
     ctx.set_timing(False)
     scene.render(W, H, spp, b, accum=accum, want_stats=True)     # warm-up: same size, so that every workspace has its final size
-    accum.zero_(); torch.cuda.synchronize()
-    t = time.perf_counter()
-    _, st = scene.render(W, H, spp, b, accum=accum, want_stats=True)
-    dt = time.perf_counter() - t
+    dt = None
+    for _ in range(2):      # two timed frames, the faster one: a frame that had to resize a workspace (first frames of a scene) is not what is quoted
+        accum.zero_(); torch.cuda.synchronize()
+        t = time.perf_counter()
+        _, st = scene.render(W, H, spp, b, accum=accum, want_stats=True)
+        d1 = time.perf_counter() - t
+        dt = d1 if dt is None else min(dt, d1)
     tm = ctx.timing()
     if timing and tm["pipeline"] == 1:     # the per-kernel split of the queue-based pipeline: a run of its own (four event records per step)
         ctx.set_timing(True)
