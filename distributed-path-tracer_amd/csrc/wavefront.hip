@@ -700,12 +700,32 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffer
 // ------------------------------------------------------------------------------------ merge
 // renderer::intersect (core/renderer.cpp:645-671) over scene::model::intersect (scene/model.cpp:20-72) with core::mesh::intersect
 // replaced by the lookup of the pair's result: the loops, comparisons and the local -> world distance are scene_traverse's.
-DEV bool wf_closest(const DevScene& S, const WfBuffers& W, uint32_t i, V3 o, V3 d, SceneHit& best) {
+// The pair results of one ray, fetched AHEAD of their use: where they start and which surfaces they belong to (head), then the first four
+// of them in one go (a ray of the 24-surface atrium has 3.2). Read one by one inside the merge loops, every result was a memory round
+// trip of its own — six to eight dependent ones per path and step in the shade kernel, at four waves per SIMD.
+constexpr uint32_t kWfPre = 4;
+struct PairPre { uint32_t first; unsigned long long mask; float4 r0, r1, r2, r3; };   // (separate fields: an indexed array would live in scratch)
+DEV void wf_pre_head(const WfBuffers& W, uint32_t i, PairPre& q) { q.first = W.first[i]; q.mask = W.mask[i]; }
+DEV void wf_pre_results(const WfBuffers& W, PairPre& q) {
+	// four unconditional 16-byte loads (clamped to the pool): what lies beyond the ray's own results is never looked at (wf_pre_get is
+	// asked for result k only when the ray has more than k)
+	const uint32_t last = W.pool_cap - 1u;
+	const uint32_t a = q.first < last ? q.first : last, b = q.first + 1u < last ? q.first + 1u : last;
+	const uint32_t c = q.first + 2u < last ? q.first + 2u : last, d = q.first + 3u < last ? q.first + 3u : last;
+	q.r0 = W.pair_hit[a]; q.r1 = W.pair_hit[b]; q.r2 = W.pair_hit[c]; q.r3 = W.pair_hit[d];
+}
+DEV float4 wf_pre_get(const WfBuffers& W, const PairPre& q, uint32_t k) {   // the k-th result of the ray
+	if (k >= kWfPre) return W.pair_hit[q.first + k];
+	const float4 a = k & 1u ? q.r1 : q.r0, b = k & 1u ? q.r3 : q.r2;
+	return k & 2u ? b : a;
+}
+
+DEV bool wf_closest(const DevScene& S, const WfBuffers& W, const PairPre& q, V3 o, V3 d, SceneHit& best) {
 	best.dist = -1.0f;
 	best.surface = -1;
 	best.tri = 0; best.b1 = 0; best.b2 = 0;
-	const unsigned long long mine = W.mask[i];
-	uint32_t p = W.first[i];
+	const unsigned long long mine = q.mask;
+	uint32_t p = 0;
 	uint32_t cur_space = 0xFFFFFFFFu;
 	V3 lo = o, ld = d, inv = d;
 	for (int m = 0; m < S.n_models; m++) {
@@ -721,7 +741,7 @@ DEV bool wf_closest(const DevScene& S, const WfBuffers& W, uint32_t i, V3 o, V3 
 		while (bits) {
 			const int u = __builtin_ctzll(bits);
 			bits &= bits - 1ull;
-			const float4 h = W.pair_hit[p++];
+			const float4 h = wf_pre_get(W, q, p++);
 			if (!(h.x >= 0)) continue;   // this surface reported no hit
 			if (h.x < nearest.t || !(nearest.t >= 0)) { nearest.t = h.x; nearest.tri = __float_as_uint(h.y); nearest.b1 = h.z; nearest.b2 = h.w; hit_surface = u; }
 		}
@@ -742,8 +762,11 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_merge_batch(DevScene S0, Inters
 	if (i >= n) return;
 	const size_t gi = first_ray + i;
 	const V3 o = mk(A.ox[gi], A.oy[gi], A.oz[gi]), d = mk(A.dx[gi], A.dy[gi], A.dz[gi]);
+	PairPre q;
+	wf_pre_head(W, i, q);
+	wf_pre_results(W, q);
 	SceneHit h;
-	const bool hit = wf_closest(S, W, i, o, d, h);
+	const bool hit = wf_closest(S, W, q, o, d, h);
 	write_hit_outputs(S, S.shade, A, gi, hit, h);
 }
 
@@ -793,9 +816,9 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_generate(DevScene S, RenderPara
 
 // renderer::intersect(shadow ray).has_hit() (renderer.cpp:509-511, intersection_worker.cpp:58-61) from the pair results: some surface
 // reports a hit whose world distance is not NaN (scene_occluded's test)
-DEV bool wf_any(const DevScene& S, const WfBuffers& W, uint32_t i, V3 o, V3 d) {
-	const unsigned long long mine = W.mask[i];
-	uint32_t p = W.first[i];
+DEV bool wf_any(const DevScene& S, const WfBuffers& W, const PairPre& q, V3 o, V3 d) {
+	const unsigned long long mine = q.mask;
+	uint32_t p = 0;
 	uint32_t cur_space = 0xFFFFFFFFu;
 	V3 lo = o, ld = d, inv = d;
 	bool occ = false;
@@ -808,7 +831,7 @@ DEV bool wf_any(const DevScene& S, const WfBuffers& W, uint32_t i, V3 o, V3 d) {
 		if (spc != cur_space) { to_space(S.spaces[spc], o, d, lo, ld, inv); cur_space = spc; }
 		while (bits) {
 			bits &= bits - 1ull;
-			const float4 h = W.pair_hit[p++];
+			const float4 h = wf_pre_get(W, q, p++);
 			if (h.x >= 0 && length(mulmv(M.basis, ld * h.x)) >= 0) occ = true;
 		}
 	}
@@ -840,7 +863,15 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_shade(DevScene S0, RenderParams
 	ShadowReq rq;
 	rq.kind = REQ_NONE;
 	if (i < n_in) {
+		// everything this entry may need that does not depend on anything else is asked for at once: the entry, its shadow request, and
+		// where the pair results of its two rays start; then the results themselves (second round trip), then the hit record (third)
 		const float4 q0 = in.q[i], q1 = in.q[cap + i], q2 = in.q[2 * (size_t)cap + i], q3 = in.q[3 * (size_t)cap + i];
+		const float4 r0 = in.r[i], r1 = in.r[cap + i], r2 = in.r[2 * (size_t)cap + i];
+		PairPre pe, ps;
+		wf_pre_head(W, i, pe);
+		wf_pre_head(W, n_in + i, ps);
+		wf_pre_results(W, ps);
+		wf_pre_results(W, pe);
 		o = mk(q0.x, q0.y, q0.z); id = wf_id(q0);
 		const uint32_t flags = wf_flags(q0);
 		d = mk(q1.x, q1.y, q1.z);
@@ -852,9 +883,8 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_shade(DevScene S0, RenderParams
 		bool occluded = false;
 		V3 x = {0, 0, 0};
 		if (flags & kWfRequest) {
-			const float4 r0 = in.r[i], r1 = in.r[cap + i], r2 = in.r[2 * (size_t)cap + i];
 			x = mk(r2.x, r2.y, r2.z);
-			occluded = wf_any(S, W, n_in + i, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z));
+			occluded = wf_any(S, W, ps, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z));
 		}
 		if (flags & kWfPending) {
 			// shadow catcher (renderer.cpp:513-519, 560-561; shading_worker.cpp:74-104): shadowed -> the path ends (trace() returns what it has,
@@ -867,7 +897,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_shade(DevScene S0, RenderParams
 			if (flags & kWfZombie) *result = make_float4(L.x, L.y, L.z, 1.0f);
 			else {
 				SceneHit h;
-				wf_closest(S, W, i, o, d, h);
+				wf_closest(S, W, pe, o, d, h);
 				const int state = shade_vertex<SUN, ALPHA, TEX, WORKER>(S, S.shade, P, __float_as_uint(key_px), __float_as_uint(key_s), depth, pass, h, o, d, T, L, rq);
 				if (state == V_ALIVE) emit = true;
 				else if (state == V_PENDING) { emit = true; out_flags = kWfPending; o = rq.x; }
