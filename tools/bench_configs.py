@@ -77,7 +77,8 @@ def run_config(ptx, ctx, name, cache, spp_scale=1.0, timing=True):
     info = scene.info()
     out = {"workload": cfg["what"] + f", {spp} spp in this run", "stand_in_geometry": cfg["scene"] != "jack", "triangles": info["n_triangles"], "kd_nodes": info["n_kd_nodes"],
            "scene_build_s": build_s, "msamples_per_s": round(samples / dt / 1e6, 1), "mrays_per_s": round(st["rays"] / dt / 1e6, 1),
-           "rays_per_sample": round(st["rays"] / samples, 4), "seconds": round(dt, 4), "rays": int(st["rays"])}
+           "rays_per_sample": round(st["rays"] / samples, 4), "seconds": round(dt, 4), "rays": int(st["rays"]),
+           "renders_in_process": 3 + (1 if (timing and tm["pipeline"] == 1) else 0)}
     if tm["pipeline"] == 1:
         k_ms = tm["classify_ms"] + tm["traverse_ms"] + tm["shade_ms"]
         out.update({"pipeline": "queue-based (classify / traverse / shade per step of a slab)", "dominant_kernel": "k_wf_traverse2",
