@@ -452,10 +452,23 @@ struct Surf { V3 pos, nrm, tan; float u, v; };
 
 // attribute interpolation of renderer::intersect — core/renderer.cpp:688-715. One round of nine 16-byte fetches from the triangle's
 // hit record (flat_scene.hpp: HitRec); the sums are the reference's, term by term.
-DEV void hit_attributes(const DevScene& S, const ShadeRec& R, uint32_t tri, float b1, float b2, Surf& out) {
+DEV void hit_attributes(const DevScene& S, const ShadeRec& R, uint32_t tri_word, float b1, float b2, Surf& out) {
 	const float b0 = 1 - b1 - b2;
-	const float4* H = S.tris + 9 * (size_t)tri;
-	const float4 A = H[0], B = H[1], C = H[2], a0 = H[3], e0 = H[4], c0 = H[5], a1 = H[6], e1 = H[7], c1 = H[8];
+	// the record: from LDS when the triangle is one of the hot ones (DevScene::hot_lds: nine LDS reads instead of a round of nine global
+	// gathers — on Cornell the 170 largest triangles take nearly all hits), else from global memory
+	const uint32_t slot = S.tri_id_mask == 0x00FFFFFFu ? tri_word >> 24 : 0xFFu;
+	float4 A, B, C, a0, e0, c0, a1, e1, c1;
+	if (S.hot_lds && slot != 0xFFu) {
+		// (an explicit LDS pointer: left generic, the two branches merge into flat loads, which go through the vector-memory path anyway)
+		typedef float f4v __attribute__((ext_vector_type(4)));
+		typedef const __attribute__((address_space(3))) f4v lds_f4;
+		lds_f4* H = (lds_f4*)S.hot_lds + 9u * slot;
+		auto ld = [&](int k) { const f4v v = H[k]; return make_float4(v.x, v.y, v.z, v.w); };
+		A = ld(0); B = ld(1); C = ld(2); a0 = ld(3); e0 = ld(4); c0 = ld(5); a1 = ld(6); e1 = ld(7); c1 = ld(8);
+	} else {
+		const float4* H = S.tris + 9 * (size_t)(tri_word & S.tri_id_mask);
+		A = H[0]; B = H[1]; C = H[2]; a0 = H[3]; e0 = H[4]; c0 = H[5]; a1 = H[6]; e1 = H[7]; c1 = H[8];
+	}
 	V3 lp = mk(A.x, A.y, A.z) * b0 + mk(B.x, B.y, B.z) * b1 + mk(C.x, C.y, C.z) * b2;
 	out.pos = mulmv(R.basis, lp) + mk(R.origin[0], R.origin[1], R.origin[2]);
 	out.u = A.w * b0 + B.w * b1 + C.w * b2;
@@ -785,15 +798,15 @@ DEV int shade_vertex(const DevScene& S, const ShadeRec* shade, const RenderParam
 }
 
 // ------------------------------------------------------------------------------------ LDS staging
-struct Staged { Geoms g; const ShadeRec* shade; };
+struct Staged { Geoms g; const ShadeRec* shade; const float4* hot; };
 
 template <int MODE>
 DEV Staged stage_geometry(const DevScene& S, unsigned char* smem) {
 	const Geom glb = {S.nodes, S.refs, S.tri_isect, S.glb_leaf_ordered != 0, true};   // tri_isect: records of ALL surfaces, per leaf reference or per triangle (upload_scene)
-	if constexpr (MODE == MODE_GLOBAL) return {{glb, glb}, S.shade};
+	if constexpr (MODE == MODE_GLOBAL) return {{glb, glb}, S.shade, nullptr};
 	else {
 		// the resident arrays (all surfaces in MODE_LDS, the ones that fit in MODE_HYBRID):
-		// [triangle records][shade records][KD nodes][leaf refs], each region a multiple of 16 B
+		// [triangle records][shade records][KD nodes][leaf refs][hot hit records], each region a multiple of 16 B
 		uint4* dst = reinterpret_cast<uint4*>(smem);
 		const uint32_t n_tri16 = S.n_res_tris * 3, n_shade16 = S.n_surfaces * (uint32_t)(sizeof(ShadeRec) / 16), n_node16 = (S.n_res_nodes + 1) / 2, n_ref16 = (S.n_res_refs + 3) / 4;
 		const uint4* src_t = reinterpret_cast<const uint4*>(S.res_tris);
@@ -803,13 +816,17 @@ DEV Staged stage_geometry(const DevScene& S, unsigned char* smem) {
 		uint4* d_s = dst + n_tri16;
 		uint4* d_n = d_s + n_shade16;
 		uint4* d_r = d_n + n_node16;
+		uint4* d_h = d_r + n_ref16;
+		const uint32_t n_hot16 = S.n_hot * 9u;
+		const uint4* src_h = reinterpret_cast<const uint4*>(S.hot_hitrec);
 		for (uint32_t i = threadIdx.x; i < n_tri16; i += blockDim.x) dst[i] = src_t[i];
 		for (uint32_t i = threadIdx.x; i < n_shade16; i += blockDim.x) d_s[i] = src_s[i];
 		for (uint32_t i = threadIdx.x; i < n_node16; i += blockDim.x) d_n[i] = src_n[i];
 		for (uint32_t i = threadIdx.x; i < n_ref16; i += blockDim.x) d_r[i] = src_r[i];
+		for (uint32_t i = threadIdx.x; i < n_hot16; i += blockDim.x) d_h[i] = src_h[i];
 		__syncthreads();
 		const Geom lds = {reinterpret_cast<const uint2*>(d_n), reinterpret_cast<const uint32_t*>(d_r), reinterpret_cast<const float4*>(dst), false, false};
-		return {{lds, glb}, reinterpret_cast<const ShadeRec*>(d_s)};
+		return {{lds, glb}, reinterpret_cast<const ShadeRec*>(d_s), S.n_hot ? reinterpret_cast<const float4*>(d_h) : nullptr};
 	}
 }
 
@@ -856,7 +873,7 @@ DEV float2* raw(Q2 q) { return q; }
 DEV void write_hit_outputs(const DevScene& S, const ShadeRec* shade, const IntersectArgs& A, size_t i, bool hit, const SceneHit& h) {
 	A.distance[i] = hit ? h.dist : -1.0f;
 	A.surface[i] = hit ? h.surface : -1;
-	A.triangle[i] = hit ? (int32_t)(h.tri - S.surfaces[h.surface].tri_base) : -1;
+	A.triangle[i] = hit ? (int32_t)((h.tri & S.tri_id_mask) - S.surfaces[h.surface].tri_base) : -1;
 	A.b0[i] = hit ? 1 - h.b1 - h.b2 : 0.f; A.b1[i] = hit ? h.b1 : 0.f; A.b2[i] = hit ? h.b2 : 0.f;
 	if (A.px || A.nx || A.u) {
 		Surf sf = {};

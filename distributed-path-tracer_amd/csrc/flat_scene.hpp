@@ -144,6 +144,7 @@ struct FlatScene {
 	std::vector<TriRec> tris;            // corners + vertex ids (host side: counts, inspection)
 	std::vector<TriIsect> tri_isect;     // intersection form (traversal)
 	std::vector<HitRec> hitrec;          // per triangle: what a hit interpolates (shading)
+	std::vector<HitRec> hot_hitrec;      // the hit records kept in LDS beside the resident geometry (largest triangles first; upload_scene)
 	CameraRec camera{};
 	SunRec sun{};
 	uint32_t kd_max_depth = 0;

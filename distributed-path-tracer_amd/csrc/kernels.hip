@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 	DevScene S = S0;
 	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;  // see struct Tables
 	const Staged st = stage_geometry<MODE>(S, g_smem);
+	S.hot_lds = st.hot;
 	const Geoms g = st.g;
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave_slot = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -552,6 +553,7 @@ __global__ void __launch_bounds__(kBlock) k_intersect_batch(DevScene S0, Interse
 	DevScene S = S0;
 	S.models = t_models; S.surfaces = t_surfaces; S.spaces = t_spaces; S.model_space = t_model_space;  // see struct Tables
 	const Staged st = stage_geometry<MODE>(S, g_smem);
+	S.hot_lds = st.hot;
 	const Geoms g = st.g;
 	const Spill spill{A.spill + (size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * (kSpillStack * 64) + (threadIdx.x & 63u)};
 	const size_t stride = (size_t)gridDim.x * blockDim.x;

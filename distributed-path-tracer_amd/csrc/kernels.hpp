@@ -43,6 +43,12 @@ struct DevScene {
 	const uint2* nodes;      // KD nodes of all surfaces (global-memory traversal)
 	const uint32_t* refs;    // unused by the kernels since the global path reads leaf-ordered records; kept for ptx_scene_get_array parity
 	const float4* tris;   // 9 per triangle: the hit record (HitRec: corners + u, normals + v, tangents)
+	// The triangle word that traversal records carry and hits report is `id | slot << 24` when tri_id_mask == 0x00FFFFFF (scenes of fewer
+	// than 2^24 triangles): slot < n_hot = the triangle's hit record is also among the n_hot records of `hot_hitrec`, which the LDS kernels
+	// stage into LDS (hot_lds, set inside the kernel) — the largest triangles, which take most hits; 0xFF = only in `tris`.
+	const float4* hot_hitrec;
+	const float4* hot_lds;
+	uint32_t n_hot, tri_id_mask;
 	const float4* tri_isect; // global-memory traversal: one TriIsect per leaf reference, in leaf order, triangle id in word 10; same allocation as `nodes`, behind them
 	uint64_t geom_bytes;     // bytes of that allocation (nodes + records [+ nodes2])
 	const uint2* nodes2;     // nullptr, or the KD nodes in 2-level blocks (wavefront.hip: BLOCK2; built when PTX_WF_BLOCK2 is set at scene creation), same allocation

@@ -107,7 +107,7 @@ struct ptx_scene {
 	ptx_ctx* ctx = nullptr;
 	FlatScene host;
 	DevBuf d_models, d_surfaces, d_materials, d_nodes, d_refs, d_tris, d_shade, d_tex, d_texels, d_lut, d_spaces, d_model_space, d_wf_order;
-	DevBuf d_res_nodes, d_res_refs, d_res_tris, d_texels_f;
+	DevBuf d_res_nodes, d_res_refs, d_res_tris, d_texels_f, d_hot;
 	DevScene dev{};
 	double lds_area_share = 0;     // share of the surfaces' box area (sum over surfaces) that belongs to LDS-resident surfaces: how much of what a ray can enter is served from LDS
 	double wf_pairs_per_ray = 0;   // queue-based pipeline: pairs (ray, entered surface) per ray seen so far on this scene, 0 = not yet measured
@@ -165,6 +165,52 @@ int upload_scene(ptx_scene* sc) {
 	HIP_TRY(up(sc->d_refs, h.kd_refs.data(), h.kd_refs.size() * 4, pad16(h.kd_refs.size() * 4)));
 	HIP_TRY(up(sc->d_tris, h.hitrec.data(), h.hitrec.size() * sizeof(HitRec), h.hitrec.size() * sizeof(HitRec)));
 	decide_mode(sc);   // sets SurfaceRec::lds_root: before the surface table goes up
+	{
+		// Hot hit records: what LDS is left beside the resident geometry takes the hit records (144 B) of the LARGEST triangles — where most
+		// hits land (Cornell: walls, boxes, light) — so that shading them costs nine LDS reads instead of a round of nine global gathers
+		// (9.8 % of the headline kernel's time, profiles/round3_clk_fused.txt). A triangle's slot travels in the top byte of the
+		// triangle word of its traversal records (id | slot << 24; 0xFF = not hot), which needs ids below 2^24. PTX_NO_HOT_HITREC: measurement.
+		const size_t n_tri = h.hitrec.size();
+		const bool packed = n_tri < ((size_t)1 << 24);
+		std::vector<uint8_t> slot_of(n_tri, 0xFF);
+		h.hot_hitrec.clear();
+		if (packed && sc->mode != MODE_GLOBAL && !getenv("PTX_NO_HOT_HITREC")) {
+			const size_t left = kLdsBudget > sc->lds_bytes ? kLdsBudget - sc->lds_bytes : 0;
+			const size_t n_hot = std::min<size_t>({(size_t)255, left / sizeof(HitRec), n_tri});
+			if (n_hot) {
+				std::vector<float> area(n_tri, 0.f);
+				for (size_t si = 0; si < h.surfaces.size(); si++) {
+					const int32_t* rg = &h.surf_range[8 * si];
+					const ModelRec& mr = h.models[h.surfaces[si].model];
+					double sc2 = 0;   // mean squared length of the basis columns: local -> world area scale (ranking only)
+					for (int k = 0; k < 9; k++) sc2 += (double)mr.basis[k] * mr.basis[k];
+					sc2 /= 3.0;
+					for (int32_t t = rg[2]; t < rg[2] + rg[3]; t++) {
+						const HitRec& r = h.hitrec[(size_t)t];
+						const double e1[3] = {(double)r.b[0] - r.a[0], (double)r.b[1] - r.a[1], (double)r.b[2] - r.a[2]}, e2[3] = {(double)r.c[0] - r.a[0], (double)r.c[1] - r.a[1], (double)r.c[2] - r.a[2]};
+						const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+						area[(size_t)t] = (float)(0.5 * std::sqrt(cx * cx + cy * cy + cz * cz) * sc2);
+					}
+				}
+				std::vector<uint32_t> idx(n_tri);
+				for (size_t i = 0; i < n_tri; i++) idx[i] = (uint32_t)i;
+				std::partial_sort(idx.begin(), idx.begin() + (std::ptrdiff_t)n_hot, idx.end(), [&](uint32_t a, uint32_t b) { return area[a] != area[b] ? area[a] > area[b] : a < b; });
+				for (size_t k = 0; k < n_hot; k++) { slot_of[idx[k]] = (uint8_t)k; h.hot_hitrec.push_back(h.hitrec[idx[k]]); }
+				sc->lds_bytes += n_hot * sizeof(HitRec);
+			}
+		}
+		auto pack = [&](std::vector<TriIsect>& recs) {
+			for (TriIsect& r : recs) {
+				uint32_t w; memcpy(&w, &r.p0, 4);
+				const uint32_t id = packed ? (w & 0x00FFFFFFu) : w;
+				w = packed ? (id | ((uint32_t)slot_of[id] << 24)) : id;
+				memcpy(&r.p0, &w, 4);
+			}
+		};
+		pack(h.tri_isect); pack(h.res_tris);
+		sc->dev.tri_id_mask = packed ? 0x00FFFFFFu : 0xFFFFFFFFu;
+		sc->dev.n_hot = (uint32_t)h.hot_hitrec.size();
+	}
 	HIP_TRY(up(sc->d_surfaces, h.surfaces.data(), h.surfaces.size() * sizeof(SurfaceRec), h.surfaces.size() * sizeof(SurfaceRec)));
 	// KD nodes and the global-memory triangle records share ONE allocation: the queue-based traverse kernel addresses both as
 	// `base + 32-bit offset` (wavefront.hip). + 16: the child-pair fetch of the last branch may read one node past the end.
@@ -237,6 +283,7 @@ int upload_scene(ptx_scene* sc) {
 		HIP_TRY(up(sc->d_res_nodes, h.res_nodes.data(), h.res_nodes.size() * 8, pad16(h.res_nodes.size() * 8)));
 		HIP_TRY(up(sc->d_res_refs, h.res_refs.data(), h.res_refs.size() * 4, pad16(h.res_refs.size() * 4)));
 		HIP_TRY(up(sc->d_res_tris, h.res_tris.data(), h.res_tris.size() * 48, h.res_tris.size() * 48));
+		HIP_TRY(up(sc->d_hot, h.hot_hitrec.data(), h.hot_hitrec.size() * sizeof(HitRec), h.hot_hitrec.size() * sizeof(HitRec)));
 	}
 	HIP_TRY(up(sc->d_shade, h.shade.data(), h.shade.size() * sizeof(ShadeRec), h.shade.size() * sizeof(ShadeRec)));
 	HIP_TRY(up(sc->d_tex, h.textures.data(), h.textures.size() * sizeof(TexRec), h.textures.size() * sizeof(TexRec)));
@@ -285,6 +332,8 @@ int upload_scene(ptx_scene* sc) {
 	d.res_nodes = (const uint2*)sc->d_res_nodes.p;
 	d.res_refs = (const uint32_t*)sc->d_res_refs.p;
 	d.res_tris = (const float4*)sc->d_res_tris.p;
+	d.hot_hitrec = (const float4*)sc->d_hot.p;
+	d.hot_lds = nullptr;
 	d.n_res_nodes = (uint32_t)h.res_nodes.size();
 	d.n_res_refs = (uint32_t)h.res_refs.size();
 	d.n_res_tris = (uint32_t)h.res_tris.size();
@@ -313,7 +362,7 @@ int upload_scene(ptx_scene* sc) {
 
 void release_scene_buffers(ptx_scene* sc) {
 	for (DevBuf* b : {&sc->d_models, &sc->d_surfaces, &sc->d_materials, &sc->d_nodes, &sc->d_refs, &sc->d_tris, &sc->d_shade, &sc->d_tex,
-	                  &sc->d_texels, &sc->d_texels_f, &sc->d_lut, &sc->d_spaces, &sc->d_model_space, &sc->d_wf_order, &sc->d_res_nodes, &sc->d_res_refs, &sc->d_res_tris})
+	                  &sc->d_texels, &sc->d_texels_f, &sc->d_lut, &sc->d_spaces, &sc->d_model_space, &sc->d_wf_order, &sc->d_res_nodes, &sc->d_res_refs, &sc->d_res_tris, &sc->d_hot})
 		b->release();
 }
 

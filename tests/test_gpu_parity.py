@@ -930,3 +930,29 @@ def test_queue_start_order_wave_clock_and_sliced_batches(ptx, ctx, monkeypatch):
         monkeypatch.delenv("PTX_WF_PAIRS_M")
         for k in h0:
             np.testing.assert_array_equal(np.asarray(h1[k]).view(np.uint32), np.asarray(h0[k]).view(np.uint32), err_msg=k + " order " + order)
+
+
+def test_hot_hit_records_in_lds_change_no_bit(ptx, ctx, scene, monkeypatch):
+    """The hit records of the largest triangles are kept in LDS beside the resident geometry (their slot travels in the top byte of the
+    triangle word). With them switched off (PTX_NO_HOT_HITREC, read at scene creation) frames and every output of ptx_intersect_batch —
+    triangle indices included — are the same bits, on the LDS-resident Cornell box and on a hybrid scene."""
+    from conftest import CORNELL, product_from_dict
+    monkeypatch.setenv("PTX_NO_HOT_HITREC", "1")
+    plain = ptx.Scene.load_gltf(ctx, CORNELL)
+    plain_h = product_from_dict(ptx, ctx, _proc().plaza_scene(level=3, sun=True, alpha=True))
+    monkeypatch.delenv("PTX_NO_HOT_HITREC")
+    hot_h = product_from_dict(ptx, ctx, _proc().plaza_scene(level=3, sun=True, alpha=True))
+    rng = np.random.default_rng(17)
+    for a, b in ((scene, plain), (hot_h, plain_h)):
+        fa, sa = a.render(160, 90, 3, 6)
+        fb, sb = b.render(160, 90, 3, 6)
+        np.testing.assert_array_equal(_bits(fa), _bits(fb))
+        assert sa["rays"] == sb["rays"]
+        cam = a.array(ptx.ARR_CAMERA)
+        d = rng.standard_normal((60_000, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+        org = np.tile(cam[:3].astype(np.float32), (len(d), 1))
+        ha, hb = a.intersect(org, d), b.intersect(org, d)
+        assert (ha["surface"] >= 0).mean() > 0.05
+        for k in ha:
+            np.testing.assert_array_equal(np.asarray(ha[k]).view(np.uint32), np.asarray(hb[k]).view(np.uint32), err_msg=k)
