@@ -329,7 +329,8 @@ __global__ void __launch_bounds__(kBlock) k_render_pass(DevScene S0, RenderParam
 					{   // the hit record's nine 16-byte pieces, fetched here so that the wait for them has a region of its own (shade_vertex then finds them in L1)
 						CLK_T0();
 						float acc = 0;
-						if (__float_as_int(hq.x) >= 0) { const float4* Hh = S.tris + 9 * (size_t)__float_as_uint(hq.y); for (int k = 0; k < 9; k++) acc += Hh[k].w; }
+						if (__float_as_int(hq.x) >= 0 && !(S.hot_lds && S.tri_id_mask == 0x00FFFFFFu && (__float_as_uint(hq.y) >> 24) != 0xFFu)) { const float4* Hh = S.tris + 9 * (size_t)(__float_as_uint(hq.y) & S.tri_id_mask);   // (hot records come from LDS inside shade_vertex)
+						 for (int k = 0; k < 9; k++) acc += Hh[k].w; }
 						CLK_WAIT();
 						if (acc == 1.2345e-30f) rays++;   // keeps the fetches alive
 						CLK_T1(6);
