@@ -38,6 +38,9 @@ constexpr int kWfLdsStack = PTX_WF_LDS_STACK;         // traversal-stack levels 
 #ifndef PTX_WF_REFILL_MIN
 #define PTX_WF_REFILL_MIN 8
 #endif
+#ifndef PTX_WF_UNROLL
+#define PTX_WF_UNROLL 2
+#endif
 constexpr uint32_t kWfRefillMin = PTX_WF_REFILL_MIN;   // idle lanes that make a hand-out of new pairs worth its instructions
 
 // PTX_WF_PROF builds: wave-level trips and active lanes per region of k_wf_traverse, added into ctl[kWfCtlProf ..] (measurement only)
@@ -513,7 +516,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffer
 	const uint64_t clock0 = W.wave_clock ? __builtin_amdgcn_s_memtime() : 0;
 	bool worked = false;
 
-	for (;;) {
+	auto trip = [&]() __attribute__((always_inline)) -> bool {   // one trip of the loop; true = the wave is through
 		WFPROF(0);
 		const uint64_t idle_m = __ballot(!busy);
 		if (more && ((uint32_t)__popcll(idle_m) >= kWfRefillMin || ~idle_m == 0)) {
@@ -590,10 +593,7 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffer
 				WFT1(2);
 			}
 		}
-		if (__ballot(busy) == 0) {
-			if (!more) break;
-			continue;
-		}
+		if (__ballot(busy) == 0) return !more;
 		worked = true;
 		if (busy) WFPROF(1);
 		// The trip itself is straight-line code under per-lane predicates: both kinds of step are computed by every lane and kept
@@ -678,6 +678,19 @@ __global__ void __launch_bounds__(kWfBlock) k_wf_traverse2(DevScene S0, WfBuffer
 		k = (pop || (branch && descend)) ? 0u : (tri ? k1 : k);
 		best_t = (pop || (branch && descend)) ? -1.0f : best_t;
 		busy = busy && !hit && !miss;
+		return false;
+	};
+	for (;;) {
+		if (trip()) break;
+#if PTX_WF_UNROLL >= 2
+		if (trip()) break;   // (several trips per iteration: the copies of the walk state at the loop's back edge are made once per iteration)
+#endif
+#if PTX_WF_UNROLL >= 3
+		if (trip()) break;
+#endif
+#if PTX_WF_UNROLL >= 4
+		if (trip()) break;
+#endif
 	}
 	if (W.wave_clock && worked && lane == 0) {   // how long this wave ran: the host compares the sum over waves with waves x the longest run
 		const uint64_t run = __builtin_amdgcn_s_memtime() - clock0;
