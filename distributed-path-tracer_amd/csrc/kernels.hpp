@@ -154,7 +154,7 @@ struct WfStream {
 constexpr uint32_t kWfIdMask = 0x0FFFFFFFu, kWfZombie = 1u << 31, kWfPending = 1u << 30, kWfRequest = 1u << 29;
 constexpr uint32_t kWfMaxSlab = 1u << 27;   // paths of a slab at most: the whole 128 Mi-path pass (the stream buffers of a slab take 224 bytes per path; ids have 28 bits)
 constexpr int kWfMaxSurfaces = 64;   // surface masks are one 64-bit word
-// persistent 256-thread workgroups of the traverse kernel: as many as can be resident (70 VGPRs and 24 KB of LDS allow 6 per CU; 8 are launched).
+// persistent 256-thread workgroups of the traverse kernel: as many as can be resident (59 VGPRs and 24 KB of LDS allow 6 per CU; 8 are launched).
 // PTX_WF_GRID=<workgroups per CU> (measurement): fewer leave room for another stream's kernels
 inline int wf_traverse_grid(int n_cu) {
 	static const int per_cu = [] { const char* e = getenv("PTX_WF_GRID"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }();

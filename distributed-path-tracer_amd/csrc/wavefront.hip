@@ -10,7 +10,7 @@
 //                  slot) grouped by surface: pair space comes from a pool sized by demand, one reservation per tile of 1024 rays
 //   k_wf_traverse  persistent waves that eat the queues: every lane walks ONE pair's tree (core::mesh::intersect, mesh.cpp:300-405)
 //                  and takes the next pair as soon as its walk ends, so lanes stay busy whatever the walk lengths; 256-thread
-//                  blocks and a traversal-only register footprint (70 VGPRs, 24 KB of LDS) give 6 waves per SIMD to cover the fetch latency; queues are
+//                  blocks and a traversal-only register footprint (59 VGPRs, 24 KB of LDS) give 6 waves per SIMD to cover the fetch latency; queues are
 //                  dealt to XCDs surface by surface so that each L2 sees a part of the geometry, and started largest tree first (DevScene::wf_order)
 //                  so that a launch ends on the queues of the short walks
 //   k_wf_merge_* / k_wf_shade   one ray per lane again: the ray's pair results (fetched ahead, four at a time) in surface order = model::intersect's loop (first
